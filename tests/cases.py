@@ -1,0 +1,88 @@
+"""Parity cases shared by tests/golden/make_golden.py (reference run), the oracle tests and
+the GPU tests.  Inputs are regenerated from seeds; only reference OUTPUTS are stored."""
+import torch
+
+_TINY = dict(n_layer=2, n_head=4, dim=256, vocab_size=1024, block_size=16, num_classes=10,
+             cls_token_num=1, model_type="c2i")
+_HD100 = dict(n_layer=2, n_head=8, dim=800, vocab_size=2048, block_size=16, num_classes=10,
+              cls_token_num=1, model_type="c2i")
+_T2I = dict(n_layer=2, n_head=4, dim=256, vocab_size=1024, block_size=16, cls_token_num=120,
+            caption_dim=64, model_type="t2i")
+_GPTB = dict(vocab_size=16384, block_size=256, num_classes=1000, cls_token_num=1, model_type="c2i")
+
+
+def _c(kwargs, **over):
+    d = dict(kwargs=kwargs, dtype="fp32", wseed=1, rseed=11, lin_std=0.05, batch=3, n_new=16,
+             cfg_scale=4.0, cfg_interval=-1, temperature=1.0, top_k=100, top_p=1.0, sample_logits=True)
+    d.update(over)
+    return d
+
+
+GPT_CASES = {
+    # free-running token ids must match bit-exactly in fp32 (SURVEY.md section 7 "hard parts")
+    "tiny_cfg4": _c(_TINY),
+    "tiny_cfg4_s2": _c(_TINY, wseed=2, rseed=12, batch=5),
+    "tiny_nocfg_temp": _c(_TINY, cfg_scale=1.0, top_k=0, temperature=0.8, batch=4),
+    "tiny_interval": _c(_TINY, cfg_scale=3.0, cfg_interval=5, top_k=50),
+    "tiny_topp": _c(_TINY, cfg_scale=2.0, top_k=0, top_p=0.9),
+    "tiny_topk_topp": _c(_TINY, cfg_scale=2.0, top_k=200, top_p=0.8),
+    "tiny_greedy": _c(_TINY, sample_logits=False),
+    "tiny_b1": _c(_TINY, batch=1, cfg_scale=1.0, top_k=20),
+    "hd100_cfg4": _c(_HD100, batch=2, top_k=300),
+    "t2i_cfg": _c(_T2I, batch=3, cfg_scale=7.5, top_k=100),
+    # bf16: reference tokens are stored and used for TEACHER FORCING; logits compared to tolerance
+    "tiny_bf16": _c(_TINY, dtype="bf16", trace_steps=list(range(16))),
+    "hd100_bf16": _c(_HD100, dtype="bf16", batch=2, top_k=300, trace_steps=list(range(16))),
+    # BASELINE.json configs[0]: LlamaGen-B 256px, single image, cfg 1.0, fp32, top-k 2000
+    "gptb_c1": _c(_GPTB, registry="GPT-B", batch=1, n_new=256, cfg_scale=1.0, top_k=2000, lin_std=0.02,
+                  trace_steps=[0, 1, 128, 255]),
+    "gptb_cfg4": _c(_GPTB, registry="GPT-B", batch=2, n_new=24, cfg_scale=4.0, top_k=2000, lin_std=0.02,
+                    trace_steps=[0, 1, 23]),
+}
+
+
+def make_gpt_inputs(case):
+    """cond (class ids or caption embeddings) and emb_masks, from the case's rseed."""
+    g = torch.Generator().manual_seed(case["rseed"] + 1000)
+    kw = case["kwargs"]
+    B = case["batch"]
+    if kw.get("model_type", "c2i") == "c2i":
+        cond = torch.randint(0, kw["num_classes"], (B,), generator=g)
+        return cond, None
+    T, C = kw["cls_token_num"], kw["caption_dim"]
+    emb = torch.randn(B, T, C, generator=g)
+    lens = torch.randint(1, T + 1, (B,), generator=g)
+    mask = torch.zeros(B, T, dtype=torch.int64)
+    for b in range(B):  # "left padding": valid tokens at the end (sample_t2i.py:92-102)
+        mask[b, T - int(lens[b]):] = 1
+    emb = emb * mask[:, :, None]
+    return emb, mask
+
+
+VQ_CASES = {
+    "vq16_4x4": dict(kind="decode", vq="VQ-16", codebook_size=16384, embed_dim=8, wseed=3, rseed=21, batch=2, h=4, w=4),
+    "vq16_3x5": dict(kind="decode", vq="VQ-16", codebook_size=16384, embed_dim=8, wseed=3, rseed=22, batch=1, h=3, w=5),
+    "vq8_4x4": dict(kind="decode", vq="VQ-8", codebook_size=16384, embed_dim=8, wseed=4, rseed=23, batch=2, h=4, w=4),
+    "argmin_6x6": dict(kind="argmin", vq="VQ-16", codebook_size=16384, embed_dim=8, wseed=3, rseed=24, batch=2, h=6, w=6),
+    "argmin_24x24": dict(kind="argmin", vq="VQ-16", codebook_size=16384, embed_dim=8, wseed=5, rseed=25, batch=2, h=24, w=24),
+}
+
+
+def make_vq_inputs(case):
+    g = torch.Generator().manual_seed(case["rseed"])
+    B, h, w = case["batch"], case["h"], case["w"]
+    if case["kind"] == "decode":
+        codes = torch.randint(0, case["codebook_size"], (B, h * w), generator=g)
+        return dict(codes=codes, shape=[B, case["embed_dim"], h, w])
+    z = torch.randn(B, case["embed_dim"], h, w, generator=g)
+    return dict(z=z)
+
+
+def noise_stream(rseed: int):
+    """The Exp(1) draws the reference consumes on CPU after torch.manual_seed(rseed):
+    one [B, V] fp32 exponential_ per sampled token (inside torch.multinomial)."""
+    g = torch.Generator().manual_seed(rseed)
+
+    def fn(shape):
+        return torch.empty(tuple(shape), dtype=torch.float32).exponential_(1, generator=g)
+    return fn

@@ -1,0 +1,109 @@
+"""Pins the CPU oracle (oracle/llamagen_oracle.py) to vectors produced by the REFERENCE itself
+(tests/golden/*.npz, made by tests/golden/make_golden.py from /root/reference).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import llamagen_oracle as O
+from tests.cases import GPT_CASES, VQ_CASES, make_gpt_inputs, make_vq_inputs, noise_stream
+from tests.util import DT, build_gpt_holder, build_vq_holder, load_golden, oracle_cfg
+
+FP32_CASES = [k for k, c in GPT_CASES.items() if c["dtype"] == "fp32"]
+BF16_CASES = [k for k, c in GPT_CASES.items() if c["dtype"] == "bf16"]
+
+
+def _run_oracle(case, teacher=None):
+    _, sd = build_gpt_holder(case)
+    model = O.GPTOracle(oracle_cfg(case), sd, DT[case["dtype"]])
+    cond, masks = make_gpt_inputs(case)
+    trace = []
+    toks = O.generate(model, cond, case["n_new"], emb_masks=masks, cfg_scale=case["cfg_scale"],
+                      cfg_interval=case["cfg_interval"], temperature=case["temperature"], top_k=case["top_k"],
+                      top_p=case["top_p"], sample_logits=case["sample_logits"],
+                      noise_fn=noise_stream(case["rseed"]), trace=trace, teacher=teacher)
+    return toks, trace
+
+
+@pytest.mark.parametrize("name", FP32_CASES)
+def test_oracle_tokens_bit_exact_fp32(name):
+    """fp32: free-running token ids identical to the reference's generate() (same seed)."""
+    case = GPT_CASES[name]
+    gold = load_golden("gpt_" + name)
+    toks, trace = _run_oracle(case)
+    assert toks.dtype == torch.int32
+    np.testing.assert_array_equal(toks.numpy(), gold["tokens"])
+    for j, s in enumerate(gold["trace_steps"]):
+        ref = gold["trace_logits"][j]
+        np.testing.assert_allclose(trace[int(s)].numpy(), ref, rtol=0, atol=1e-5 * max(1.0, np.abs(ref).max()))
+
+
+@pytest.mark.parametrize("name", BF16_CASES)
+def test_oracle_logits_teacher_forced_bf16(name):
+    """bf16: no independent GEMM reproduces another's token stream, so the
+    reference tokens are fed back (teacher forcing) and every step's logits must agree to
+    bf16 resolution: <= 2 bf16 ulps of the largest logit, mean error well below one ulp."""
+    case = GPT_CASES[name]
+    gold = load_golden("gpt_" + name)
+    toks, trace = _run_oracle(case, teacher=torch.from_numpy(gold["tokens"]))
+    ref = gold["trace_logits"]
+    got = np.stack([trace[int(s)].numpy() for s in gold["trace_steps"]])
+    scale = np.abs(ref).max()
+    ulp = scale * 2.0 ** -8
+    err = np.abs(got - ref)
+    assert err.max() <= 4 * ulp, (err.max(), ulp)
+    assert err.mean() <= 0.25 * ulp, (err.mean(), ulp)
+    agree = (toks.numpy() == gold["tokens"]).mean()
+    assert agree >= 0.8, agree  # sampler given near-identical logits and the same noise
+
+
+def test_multinomial_is_argmax_p_over_q():
+    """The identity the whole sampler design rests on."""
+    torch.manual_seed(5)
+    p = torch.softmax(torch.randn(7, 1024), -1)
+    torch.manual_seed(123)
+    a = torch.multinomial(p, num_samples=1)
+    torch.manual_seed(123)
+    q = torch.empty_like(p).exponential_(1)
+    assert torch.equal(a, torch.argmax(p / q, dim=-1, keepdim=True))
+    g = torch.Generator().manual_seed(123)
+    q2 = torch.empty_like(p).exponential_(1, generator=g)
+    assert torch.equal(q, q2)
+
+
+@pytest.mark.parametrize("name", [k for k, c in VQ_CASES.items() if c["kind"] == "decode"])
+def test_oracle_vq_decode(name):
+    case = VQ_CASES[name]
+    gold = load_golden("vq_" + name)
+    m, sd = build_vq_holder(case)
+    inp = make_vq_inputs(case)
+    img = O.vq_decode_code(sd, inp["codes"], inp["shape"], ch_mult=tuple(m.config.decoder_ch_mult))
+    np.testing.assert_allclose(img.numpy(), gold["image"], rtol=0, atol=5e-5)
+    u8 = O.to_uint8_hwc(img).numpy()
+    assert (np.abs(u8.astype(np.int32) - gold["uint8"].astype(np.int32)) <= 1).all()
+    assert (u8 != gold["uint8"]).mean() < 1e-3
+
+
+@pytest.mark.parametrize("name", [k for k, c in VQ_CASES.items() if c["kind"] == "argmin"])
+def test_oracle_vq_argmin(name):
+    case = VQ_CASES[name]
+    gold = load_golden("vq_" + name)
+    _, sd = build_vq_holder(case)
+    z = make_vq_inputs(case)["z"]
+    idx = O.codebook_argmin(sd["quantize.embedding.weight"], z)
+    np.testing.assert_array_equal(idx.numpy(), gold["indices"])
+    zq = O.get_codebook_entry(sd["quantize.embedding.weight"], idx, list(z.shape))
+    np.testing.assert_allclose(zq.numpy()[:1], gold["zq_head"], rtol=0, atol=1e-7)
+
+
+def test_oracle_edge_cases():
+    cb = torch.randn(64, 8)
+    assert O.codebook_argmin(cb, torch.zeros(0, 8, 2, 2)).numel() == 0          # empty batch
+    z = O.l2_normalize(cb)[[5, 9, 63, 0]].t().reshape(1, 8, 2, 2)               # exact codebook hits
+    assert O.codebook_argmin(cb, z).tolist() == [5, 9, 63, 0]
+    lg = torch.tensor([[1.0, 3.0, 3.0, 2.0, -1.0]])
+    f = O.top_k_top_p_filtering(lg, top_k=1)                                     # ties at threshold kept
+    assert torch.isfinite(f).sum().item() == 2
+    f = O.top_k_top_p_filtering(lg, top_k=99)                                    # k clamped to V
+    assert torch.isfinite(f).all()
+    fr = O.precompute_freqs_cis_2d(4, 64, 10000.0, 3)
+    assert fr.shape == (3 + 16, 32, 2) and (fr[:3] == 0).all() and (fr[3, :, 0] == 1).all()

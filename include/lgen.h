@@ -1,0 +1,83 @@
+/* lgen.h -- C ABI of the MI355X-native LlamaGen sampling library (liblgen_hip.so).
+ *
+ * The reference (FoundationVision/LlamaGen) has no native/FFI layer on this path: the boundary a
+ * replacement sits behind is its Python API.  This header is the C ABI
+ * underneath our Python host mirror (llamagen_amd/): `extern "C"`, raw device pointers + sizes,
+ * a `hipStream_t` passed as void*, no torch types, no allocation, no synchronisation, no global
+ * mutable state; every entry point only enqueues kernels on the given stream (hipGraph-capture
+ * safe) and returns 0 or a hipError_t / LGEN_ERR_* code.  Each entry point cites the reference
+ * op sequence it replaces (paths relative to the reference repository root).
+ *
+ * Fragment-packed layouts ("chunk" = 1 KiB = [16 rows][KC k] in MFMA operand order, lane =
+ * g*16 + r holds row r, k-slice g*EPL..+EPL; bf16: KC=32, EPL=8; fp32: KC=16, EPL=4):
+ *   weights      WP[N/16][K/KC][64][EPL]
+ *   activations  XP[K/KC][MTs][64][EPL]      (row m lives in m-tile m/16, lane-row m%16)
+ */
+#ifndef LGEN_H
+#define LGEN_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LGEN_ABI_VERSION 1
+#define LGEN_BF16 0
+#define LGEN_F32 1
+
+#define LGEN_ERR_BAD_ARG (-1)
+#define LGEN_ERR_UNSUPPORTED (-2)
+
+/* epilogues of lgen_gemm */
+#define LGEN_EPI_ROWS 0   /* out[M][N] row-major, storage dtype (lm_head: gpt.py:367-368)            */
+#define LGEN_EPI_PACKED 1 /* out = XP of width N                                                    */
+#define LGEN_EPI_GELU 2   /* out = XP of gelu_tanh(.) (CaptionEmbedder MLP fc1, gpt.py:118-131)      */
+#define LGEN_EPI_RES 3    /* out (XP, in/out) += result: wo / w2 + residual (gpt.py:238-240,255-256) */
+#define LGEN_EPI_SWIGLU 4 /* W = row-tile-interleaved w1||w3, out = XP of silu(w1x)*w3x (gpt.py:167) */
+
+int lgen_abi_version(void);
+
+/* ---- GPT decode step ------------------------------------------------------------------- */
+
+/* nn.Embedding gather (gpt.py:78-83 LabelEmbedder / :351 tok_embeddings) -> packed residual stream.
+ * table [rows][d] storage dtype, idx int32 [M] (device), hp = XP[d/KC][MTs]. */
+int lgen_embed_pack(const void* table, const int* idx, void* hp, int M, int MTs, int d, int rows, int dtype,
+                    void* stream);
+
+/* RMSNorm.forward (gpt.py:143-148) on XP -> XP, fp32 math, two storage roundings. */
+int lgen_rmsnorm(const void* hp, const void* weight, void* xnp, int MTs, int d, float eps, int dtype, void* stream);
+
+/* Bias-free nn.Linear (gpt.py:161-163,199-200,287) out = x . W^T with fused epilogue, fp32
+ * accumulate on MFMA, one storage rounding of the linear output.  (mt, nt, kw) = tile shape:
+ * m-tiles per workgroup (divides MTs), n-tiles per workgroup, waves splitting K. */
+int lgen_gemm(const void* wp, const void* xp, void* out, int M, int MTs, int N, int K, int epilogue_kind, int dtype,
+              int mt, int nt, int kw, void* stream);
+
+/* Attention.forward front half (gpt.py:214-226): wqkv GEMM + apply_rotary_emb(q,k) (gpt.py:420-430)
+ * + KVCache.update at *pos_ptr (gpt.py:177-185).  q_out [MTs*16][H][hdp]; caches [B2][H][S8][hdp];
+ * freqs [P][hd/2][2] fp32 from precompute_freqs_cis_2d (gpt.py:404-417). */
+int lgen_gemm_qkv_rope(const void* wp, const void* xp, void* q_out, void* k_cache, void* v_cache, const float* freqs,
+                       const int* pos_ptr, int M, int MTs, int d, int n_head, int hd, int hdp, int S8, int dtype,
+                       int mt, int nt, int kw, void* stream);
+
+/* Attention.forward back half (gpt.py:229-236): repeat_interleave + math-backend SDPA with
+ * causal_mask[:, pos] -- here: single-query attention over the first *pos_ptr+1 cache slots.
+ * mask: null = pure causal, else the reference's causal_mask [B2][S8][S8] (1 byte per entry, as
+ * modified by generate.py:154-163 for t2i emb_masks); row *pos_ptr of it gates the keys. */
+int lgen_attn_decode(const void* q, const void* k_cache, const void* v_cache, void* out_packed, const int* pos_ptr,
+                     const unsigned char* mask, int B2, int MTs, int n_head, int hd, int hdp, int S8, int dtype,
+                     void* stream);
+
+/* generate.py:79-86,94-99 (CFG mix) + :57-66 sample() + :16-54 top_k_top_p_filtering +
+ * torch.multinomial(1) == argmax(p / noise).  logits [>=2B][V] storage dtype (rows [0,B) cond,
+ * [B,2B) uncond when use_cfg); noise [B][V] fp32 Exp(1) draws; state = {pos, step} device ints.
+ * Writes cur_tok[b] (and cur_tok[B+b]), seq[b][step]; advance != 0 bumps pos and step. */
+int lgen_sample(const void* logits, const float* noise, int* cur_tok, int* seq, int* state, int B, int V,
+                int seq_stride, int use_cfg, float cfg_scale, int cfg_interval, float temperature, int top_k,
+                float top_p, int greedy, int advance, int dtype, void* stream);
+
+int lgen_advance_state(int* state, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LGEN_H */

@@ -1,0 +1,270 @@
+// Wave-reduction kernels of the GPT decode step (HBM/latency-bound, no MFMA):
+//   lgen_embed_pack   token / class-embedding gather -> fragment-packed residual stream
+//                     (autoregressive/models/gpt.py:78-83 LabelEmbedder, :351 tok_embeddings)
+//   lgen_rmsnorm      RMSNorm on the packed layout (gpt.py:137-148), two bf16 rounding points
+//   lgen_attn_decode  KV-cached single-query attention over kv_len = pos+1 keys only
+//                     (gpt.py:229-236 repeat_interleave + math-SDPA with causal_mask[:, pos])
+#include "lgen_common.h"
+#include "../../include/lgen.h"
+
+// ---------------------------------------------------------------------------------------------
+// embedding gather: hp[k-chunk][mt][lane] <- table[idx[m]][k..]   (16 B per thread)
+// ---------------------------------------------------------------------------------------------
+template <typename D>
+__global__ __launch_bounds__(256) void embed_pack_kernel(const uint4* __restrict__ table, const int* __restrict__ idx,
+                                                         uint4* __restrict__ hp, int M, int MTs, int d, int rows) {
+    const int KCH = d / D::KC;
+    const int total = KCH * MTs * 64;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+        const int lane = t & 63;
+        const int mt = (t >> 6) % MTs;
+        const int kc = (t >> 6) / MTs;
+        const int m = mt * 16 + (lane & 15);
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (m < M) {
+            int row = idx[m];
+            row = row < 0 ? 0 : (row >= rows ? rows - 1 : row);
+            v = table[((size_t)row * d + kc * D::KC + (lane >> 4) * D::EPL) / D::EPL];
+        }
+        hp[t] = v;
+    }
+}
+
+extern "C" int lgen_embed_pack(const void* table, const int* idx, void* hp, int M, int MTs, int d, int rows,
+                               int dtype, void* stream) {
+    if (M > MTs * 16 || d % 32) return LGEN_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == LGEN_BF16) {
+        int total = (d / 32) * MTs * 64;
+        hipLaunchKernelGGL(embed_pack_kernel<BF16>, dim3((total + 255) / 256), dim3(256), 0, st, (const uint4*)table, idx,
+                           (uint4*)hp, M, MTs, d, rows);
+    } else if (dtype == LGEN_F32) {
+        int total = (d / 16) * MTs * 64;
+        hipLaunchKernelGGL(embed_pack_kernel<F32>, dim3((total + 255) / 256), dim3(256), 0, st, (const uint4*)table, idx,
+                           (uint4*)hp, M, MTs, d, rows);
+    } else {
+        return LGEN_ERR_BAD_ARG;
+    }
+    LGEN_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// RMSNorm on packed activations.  One workgroup per 16-row m-tile; wave w owns k-chunks
+// w, w+NW, ... (each a coalesced 1 KiB load kept in registers), row sums of squares reduce over
+// the 4 lane groups (xor 16, 32) and then over waves through LDS.
+// ---------------------------------------------------------------------------------------------
+#define RMS_MAXC 16
+template <typename D>
+__global__ __launch_bounds__(1024) void rmsnorm_kernel(const uint4* __restrict__ hp, const void* __restrict__ w,
+                                                       uint4* __restrict__ xn, int MTs, int d, float eps) {
+    __shared__ float part[16][16];
+    __shared__ float rinv[16];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, NW = blockDim.x >> 6;
+    const int mt = blockIdx.x;
+    const int KCH = d / D::KC;
+    uint4 v[RMS_MAXC];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < RMS_MAXC; ++i) {
+        const int kc = wv + i * NW;
+        if (kc < KCH) {
+            v[i] = hp[((size_t)kc * MTs + mt) * 64 + lane];
+            float f[D::EPL];
+            D::unpack(v[i], f);
+#pragma unroll
+            for (int e = 0; e < D::EPL; ++e) ss += f[e] * f[e];
+        }
+    }
+    ss += __shfl_xor(ss, 16, 64);
+    ss += __shfl_xor(ss, 32, 64);
+    if (lane < 16) part[wv][lane] = ss;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        float t = 0.f;
+        for (int i = 0; i < NW; ++i) t += part[i][threadIdx.x];
+        rinv[threadIdx.x] = 1.0f / sqrtf(t / (float)d + eps);
+    }
+    __syncthreads();
+    const float ri = rinv[lane & 15];
+#pragma unroll
+    for (int i = 0; i < RMS_MAXC; ++i) {
+        const int kc = wv + i * NW;
+        if (kc < KCH) {
+            float f[D::EPL], o[D::EPL];
+            D::unpack(v[i], f);
+            const int k = kc * D::KC + (lane >> 4) * D::EPL;
+#pragma unroll
+            for (int e = 0; e < D::EPL; ++e) o[e] = D::rnd(f[e] * ri) * D::ld(w, k + e);
+            xn[((size_t)kc * MTs + mt) * 64 + lane] = D::pack(o);
+        }
+    }
+}
+
+extern "C" int lgen_rmsnorm(const void* hp, const void* weight, void* xnp, int MTs, int d, float eps, int dtype,
+                            void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int kcsz = dtype == LGEN_BF16 ? 32 : 16;
+    if (d % kcsz) return LGEN_ERR_BAD_ARG;
+    const int KCH = d / kcsz;
+    int nw = 4;
+    while (nw < 16 && nw * RMS_MAXC < KCH) nw *= 2;
+    if (nw * RMS_MAXC < KCH) return LGEN_ERR_BAD_ARG;
+    if (dtype == LGEN_BF16)
+        hipLaunchKernelGGL(rmsnorm_kernel<BF16>, dim3(MTs), dim3(64 * nw), 0, st, (const uint4*)hp, weight, (uint4*)xnp,
+                           MTs, d, eps);
+    else if (dtype == LGEN_F32)
+        hipLaunchKernelGGL(rmsnorm_kernel<F32>, dim3(MTs), dim3(64 * nw), 0, st, (const uint4*)hp, weight, (uint4*)xnp,
+                           MTs, d, eps);
+    else
+        return LGEN_ERR_BAD_ARG;
+    LGEN_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Decode attention.  One workgroup (4 waves) per (batch row, head).  K and V of that (b, h) are
+// contiguous [S8][hdp] streams; a wave-wide 16-byte-per-lane load covers KPL = 64/LPK keys
+// (LPK lanes per key).  Each wave walks its share of the keys in groups of 4 loads (K and V
+// issued together), keeps an online-softmax state (m, l, acc) and the four states merge through
+// LDS.  fp32 math from storage-dtype inputs, one rounding at the output (math-SDPA semantics,
+// incl. ATen's sqrt(scale) pre-scaling of both q and k).  Only kv_len = pos+1 keys are read --
+// the reference reads (and copies) all S8 slots and masks.
+// ---------------------------------------------------------------------------------------------
+struct AttnArgs {
+    const void* q;       // [M][H][hdp]
+    const void* kc;      // [B2][H][S8][hdp]
+    const void* vc;
+    void* out;           // packed [d/KC][MTs][64][EPL]
+    const int* pos_ptr;
+    const unsigned char* mask;  // null (pure causal) or causal_mask [B2][S8][S8] bytes: row `pos` is read
+    int H, hd, hdp, S8, MTs;
+    float sf;            // sqrt(1/sqrt(hd))
+};
+
+#define ATT_NW 4
+#define ATT_CH 4
+template <typename D, int LPK>
+__global__ __launch_bounds__(64 * ATT_NW) void attn_decode_kernel(AttnArgs a) {
+    constexpr int KPL = 64 / LPK;            // keys per wave-load
+    constexpr int EPL = D::EPL;
+    __shared__ float s_m[ATT_NW], s_l[ATT_NW];
+    __shared__ float s_acc[ATT_NW][LPK * EPL];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+    const int pos = *a.pos_ptr;
+    const int kvlen = pos + 1;
+    const int part = lane % LPK, kin = lane / LPK;
+    const size_t rowbase = ((size_t)b * a.H + h) * a.S8;
+    const uint4* kp = (const uint4*)a.kc + (rowbase * a.hdp) / EPL;
+    const uint4* vp = (const uint4*)a.vc + (rowbase * a.hdp) / EPL;
+    const int lpr = a.hdp / EPL;             // 16-byte pieces per key row (== LPK)
+    float qf[EPL];
+    {
+        uint4 qv = ((const uint4*)a.q)[(((size_t)b * a.H + h) * a.hdp) / EPL + part];
+        D::unpack(qv, qf);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) qf[e] *= a.sf;
+    }
+    const unsigned char* pm = a.mask ? a.mask + ((size_t)b * a.S8 + pos) * a.S8 : nullptr;
+
+    float m_run = -1e30f, l_run = 0.f, acc[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
+
+    const int nchunks = (kvlen + KPL - 1) / KPL;
+    for (int c0 = wv * ATT_CH; c0 < nchunks; c0 += ATT_NW * ATT_CH) {
+        uint4 kv[ATT_CH], vv[ATT_CH];
+        int key[ATT_CH];
+#pragma unroll
+        for (int j = 0; j < ATT_CH; ++j) {
+            key[j] = (c0 + j) * KPL + kin;
+            int kk = key[j] < a.S8 ? key[j] : a.S8 - 1;
+            kv[j] = kp[(size_t)kk * lpr + part];
+            vv[j] = vp[(size_t)kk * lpr + part];
+        }
+        float s[ATT_CH];
+        float tmax = -1e30f;
+#pragma unroll
+        for (int j = 0; j < ATT_CH; ++j) {
+            float kf[EPL];
+            D::unpack(kv[j], kf);
+            float dot = 0.f;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) dot = fmaf(qf[e], kf[e] * a.sf, dot);
+#pragma unroll
+            for (int o = 1; o < LPK; o <<= 1) dot += __shfl_xor(dot, o, 64);
+            bool vis = key[j] < kvlen;
+            if (pm && vis) vis = pm[key[j]] != 0;
+            s[j] = vis ? dot : -1e30f;
+            tmax = fmaxf(tmax, s[j]);
+        }
+#pragma unroll
+        for (int o = LPK; o < 64; o <<= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, o, 64));
+        const float m_new = fmaxf(m_run, tmax);
+        const float scale = expf(m_run - m_new);
+        l_run *= scale;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) acc[e] *= scale;
+#pragma unroll
+        for (int j = 0; j < ATT_CH; ++j) {
+            const float p = s[j] > -1e29f ? expf(s[j] - m_new) : 0.f;
+            l_run += p;
+            float vf[EPL];
+            D::unpack(vv[j], vf);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) acc[e] = fmaf(p, vf[e], acc[e]);
+        }
+        m_run = m_new;
+    }
+    // combine the KPL key groups of this wave (lanes with equal `part`)
+#pragma unroll
+    for (int o = LPK; o < 64; o <<= 1) {
+        l_run += __shfl_xor(l_run, o, 64);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
+    }
+    if (lane < LPK) {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) s_acc[wv][lane * EPL + e] = acc[e];
+    }
+    if (lane == 0) { s_m[wv] = m_run; s_l[wv] = l_run; }
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < a.hd) {
+        float M = s_m[0];
+#pragma unroll
+        for (int i = 1; i < ATT_NW; ++i) M = fmaxf(M, s_m[i]);
+        float L = 0.f, o = 0.f;
+#pragma unroll
+        for (int i = 0; i < ATT_NW; ++i) {
+            const float f = expf(s_m[i] - M);
+            L += s_l[i] * f;
+            o += s_acc[i][t] * f;
+        }
+        o = o / L;
+        D::st(a.out, D::xp_off(h * a.hd + t, b >> 4, b & 15, a.MTs), o);
+    }
+}
+
+extern "C" int lgen_attn_decode(const void* q, const void* k_cache, const void* v_cache, void* out_packed,
+                                const int* pos_ptr, const unsigned char* mask, int B2, int MTs, int n_head,
+                                int hd, int hdp, int S8, int dtype, void* stream) {
+    AttnArgs a{q, k_cache, v_cache, out_packed, pos_ptr, mask, n_head, hd, hdp, S8, MTs, 0.f};
+    a.sf = sqrtf(1.0f / sqrtf((float)hd));
+    hipStream_t st = (hipStream_t)stream;
+    const int epl = dtype == LGEN_BF16 ? 8 : 4;
+    if (dtype != LGEN_BF16 && dtype != LGEN_F32) return LGEN_ERR_BAD_ARG;
+    if (hdp % epl || hd > hdp || hd > 64 * ATT_NW || B2 > MTs * 16) return LGEN_ERR_BAD_ARG;
+    const int lpk = hdp / epl;
+    dim3 grid(B2 * n_head), block(64 * ATT_NW);
+#define LGEN_ATT(DT, L) hipLaunchKernelGGL((attn_decode_kernel<DT, L>), grid, block, 0, st, a)
+    if (dtype == LGEN_BF16 && lpk == 8) LGEN_ATT(BF16, 8);
+    else if (dtype == LGEN_BF16 && lpk == 16) LGEN_ATT(BF16, 16);
+    else if (dtype == LGEN_F32 && lpk == 16) LGEN_ATT(F32, 16);
+    else if (dtype == LGEN_F32 && lpk == 32) LGEN_ATT(F32, 32);
+    else return LGEN_ERR_BAD_ARG;
+#undef LGEN_ATT
+    LGEN_CHECK_LAUNCH();
+    return 0;
+}

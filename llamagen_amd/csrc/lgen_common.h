@@ -1,0 +1,130 @@
+// Common device helpers for the lgen HIP library (gfx950 / CDNA4 only).
+//
+// Storage dtypes: BF16 (the reference's default --precision bf16) and F32
+// (--precision none, the bit-exact-token parity mode).  Arithmetic is always fp32 with
+// the reference's storage rounding points reproduced explicitly.
+//
+// Fragment-packed layouts (DESIGN.md "data layout in HBM"):
+//   one "chunk" = what one wave-wide 16-byte-per-lane load brings in = 1 KiB =
+//   a [16 rows x KC k] tile in MFMA operand order: lane = g*16 + r holds row r,
+//   k-slice [g*EPL, g*EPL+EPL).  KC = 32 / EPL = 8 for bf16 (mfma_f32_16x16x32_bf16),
+//   KC = 16 / EPL = 4 for fp32 (4 x mfma_f32_16x16x4_f32, k-slot j <-> element j).
+//   weights      WP[nt][kc][lane][EPL]   (nt = 16-row tile of N)
+//   activations  XP[kc][mt][lane][EPL]   (mt = 16-row tile of M, M padded to MT*16)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+#define LGEN_DEV __device__ __forceinline__
+
+LGEN_DEV float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+LGEN_DEV uint16_t f2bf(float f) {  // round-to-nearest-even, NaN preserved
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+LGEN_DEV float rnd_bf(float f) { return bf2f(f2bf(f)); }
+
+struct BF16 {
+    static constexpr int EPL = 8;    // elements per lane per 16-byte load
+    static constexpr int KC = 32;    // k elements per chunk
+    static constexpr int ESZ = 2;
+    static constexpr int CODE = 0;
+    typedef uint16_t elem_t;
+    LGEN_DEV static float rnd(float f) { return rnd_bf(f); }
+    LGEN_DEV static float ld(const void* p, size_t i) { return bf2f(((const uint16_t*)p)[i]); }
+    LGEN_DEV static void st(void* p, size_t i, float v) { ((uint16_t*)p)[i] = f2bf(v); }
+    // unpack the EPL values of one lane's 16 bytes
+    LGEN_DEV static void unpack(const uint4& u, float (&f)[8]) {
+        f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
+        f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
+        f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
+        f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+    }
+    LGEN_DEV static uint4 pack(const float (&f)[8]) {
+        uint4 u;
+        u.x = (uint32_t)f2bf(f[0]) | ((uint32_t)f2bf(f[1]) << 16);
+        u.y = (uint32_t)f2bf(f[2]) | ((uint32_t)f2bf(f[3]) << 16);
+        u.z = (uint32_t)f2bf(f[4]) | ((uint32_t)f2bf(f[5]) << 16);
+        u.w = (uint32_t)f2bf(f[6]) | ((uint32_t)f2bf(f[7]) << 16);
+        return u;
+    }
+    // store 4 consecutive elements (8 bytes)
+    LGEN_DEV static void st4(void* p, size_t i, float a, float b, float c, float d) {
+        uint2 u;
+        u.x = (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
+        u.y = (uint32_t)f2bf(c) | ((uint32_t)f2bf(d) << 16);
+        *(uint2*)((uint16_t*)p + i) = u;
+    }
+    LGEN_DEV static void ld4(const void* p, size_t i, float& a, float& b, float& c, float& d) {
+        uint2 u = *(const uint2*)((const uint16_t*)p + i);
+        a = __uint_as_float(u.x << 16); b = __uint_as_float(u.x & 0xffff0000u);
+        c = __uint_as_float(u.y << 16); d = __uint_as_float(u.y & 0xffff0000u);
+    }
+    // element offset inside a packed activation buffer of (m-tile mt, lane-row r, k index)
+    LGEN_DEV static size_t xp_off(int k, int mt, int r, int MTs) {
+        return ((size_t)((k >> 5) * MTs + mt) * 64 + ((k >> 3) & 3) * 16 + r) * 8 + (k & 7);
+    }
+    LGEN_DEV static f32x4_t mma(const uint4& a, const uint4& b, f32x4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                        __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
+};
+
+struct F32 {
+    static constexpr int EPL = 4;
+    static constexpr int KC = 16;
+    static constexpr int ESZ = 4;
+    static constexpr int CODE = 1;
+    typedef float elem_t;
+    LGEN_DEV static float rnd(float f) { return f; }
+    LGEN_DEV static float ld(const void* p, size_t i) { return ((const float*)p)[i]; }
+    LGEN_DEV static void st(void* p, size_t i, float v) { ((float*)p)[i] = v; }
+    LGEN_DEV static void unpack(const uint4& u, float (&f)[4]) {
+        f[0] = __uint_as_float(u.x); f[1] = __uint_as_float(u.y);
+        f[2] = __uint_as_float(u.z); f[3] = __uint_as_float(u.w);
+    }
+    LGEN_DEV static uint4 pack(const float (&f)[4]) {
+        return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+    }
+    LGEN_DEV static void st4(void* p, size_t i, float a, float b, float c, float d) {
+        *(float4*)((float*)p + i) = make_float4(a, b, c, d);
+    }
+    LGEN_DEV static void ld4(const void* p, size_t i, float& a, float& b, float& c, float& d) {
+        float4 v = *(const float4*)((const float*)p + i);
+        a = v.x; b = v.y; c = v.z; d = v.w;
+    }
+    LGEN_DEV static size_t xp_off(int k, int mt, int r, int MTs) {
+        return ((size_t)((k >> 4) * MTs + mt) * 64 + ((k >> 2) & 3) * 16 + r) * 4 + (k & 3);
+    }
+    LGEN_DEV static f32x4_t mma(const uint4& a, const uint4& b, f32x4_t c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+        return c;
+    }
+};
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+LGEN_DEV uint4 ldg_nt(const uint4* p) {  // streamed-once data (weights): non-temporal
+    u32x4_t v = __builtin_nontemporal_load((const u32x4_t*)p);
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
+
+LGEN_DEV float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+LGEN_DEV float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+#define LGEN_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)

@@ -1,3 +1,59 @@
-"""placeholder; filled in with the engine"""
-def generate(*a, **k):
-    raise NotImplementedError
+"""generate(): drop-in for autoregressive/models/generate.py:126-176 on the HIP engine.
+
+Same signature, same semantics (CFG batch doubling :129-131/:136-138, cache setup :147-152, t2i
+emb_masks folding :154-163, prefill :168-170, N-1 decode steps :172-174, int32 [B, N] result on
+cond.device), same consumption of the device's default torch generator (one [B, V] fp32
+exponential_ per sampled token, exactly what torch.multinomial draws).  The per-token Python loop of
+the reference (decode_n_tokens, :105-123) becomes replays of one captured hipGraph with device-side
+position / step counters; sampling (sample(), top_k_top_p_filtering, CFG mix) is one HIP kernel.
+"""
+from __future__ import annotations
+
+import torch
+
+
+@torch.no_grad()
+def generate(model, cond, max_new_tokens, emb_masks=None, cfg_scale=1.0, cfg_interval=-1, **sampling_kwargs):
+    temperature = sampling_kwargs.pop("temperature", 1.0)
+    top_k = sampling_kwargs.pop("top_k", 0)
+    top_p = sampling_kwargs.pop("top_p", 1.0)
+    sample_logits = sampling_kwargs.pop("sample_logits", True)
+    noise_seq = sampling_kwargs.pop("_noise_seq", None)  # test hook: inject the Exp(1) draws [N, B, V]
+    if sampling_kwargs:
+        raise TypeError(f"unexpected sampling arguments: {sorted(sampling_kwargs)}")
+
+    if model.model_type == "c2i":
+        if cfg_scale > 1.0:
+            cond_null = torch.ones_like(cond) * model.num_classes
+            cond_combined = torch.cat([cond, cond_null])
+        else:
+            cond_combined = cond
+        T = 1
+    elif model.model_type == "t2i":
+        if cfg_scale > 1.0:
+            cond_null = torch.zeros_like(cond) + model.cls_embedding.uncond_embedding.to(cond.dtype)
+            cond_combined = torch.cat([cond, cond_null])
+        else:
+            cond_combined = cond
+        T = cond.shape[1]
+    else:
+        raise Exception("please check model type")
+
+    T_new = T + max_new_tokens
+    max_batch_size = cond.shape[0]
+    max_batch_size_cfg = max_batch_size * 2 if cfg_scale > 1.0 else max_batch_size
+    model.setup_caches(max_batch_size=max_batch_size_cfg, max_seq_length=T_new,
+                       dtype=model.tok_embeddings.weight.dtype)
+
+    masks = None
+    if emb_masks is not None:
+        assert emb_masks.shape[0] == max_batch_size
+        assert emb_masks.shape[-1] == T
+        masks = torch.cat([emb_masks, emb_masks]) if cfg_scale > 1.0 else emb_masks
+
+    sp = dict(use_cfg=cfg_scale > 1.0, cfg_scale=float(cfg_scale), cfg_interval=int(cfg_interval),
+              temperature=float(temperature), top_k=int(top_k), top_p=float(top_p),
+              sample_logits=bool(sample_logits))
+    if noise_seq is not None:
+        sp["_noise_seq"] = noise_seq
+    return model._engine.generate(model, cond_combined, max_batch_size, max_new_tokens, masks, sp)

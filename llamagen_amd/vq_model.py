@@ -178,9 +178,9 @@ class VQModel(nn.Module):
         self._engine = None
 
     def _eng(self):
-        from .vq_engine import VQEngine
         if self.post_quant_conv.weight.device.type != "cuda":
             raise RuntimeError("llamagen_amd.VQModel runs only on an AMD GPU through the HIP library (no CPU fallback)")
+        from .vq_engine import VQEngine
         if self._engine is None or not self._engine.compatible(self):
             self._engine = VQEngine(self)
         return self._engine

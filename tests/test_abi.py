@@ -1,0 +1,76 @@
+"""CPU-only: the C-ABI library loads and exports every symbol include/lgen.h declares; host logic
+(packing, registries, state_dict keys, tile heuristics) without any compute call."""
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from llamagen_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    return _lib.lib()
+
+
+def _header_symbols():
+    out = []
+    for fn in sorted(os.listdir(os.path.join(ROOT, "include"))):
+        txt = open(os.path.join(ROOT, "include", fn)).read()
+        out += re.findall(r"^int\s+(lgen_\w+)\s*\(", txt, flags=re.M)
+    return out
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    from llamagen_amd import _lib
+    syms = _header_symbols()
+    assert len(syms) >= 8
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/ but not exported"
+        assert s in _lib.SIGNATURES, f"{s} has no ctypes signature"
+    assert lib.lgen_abi_version() == 1
+
+
+def test_header_arg_counts_match_ctypes_signatures():
+    from llamagen_amd import _lib
+    for fn in sorted(os.listdir(os.path.join(ROOT, "include"))):
+        txt = open(os.path.join(ROOT, "include", fn)).read()
+        for name, args in re.findall(r"^int\s+(lgen_\w+)\s*\(([^;]*?)\);", txt, flags=re.M | re.S):
+            n = 0 if args.strip() == "void" else len([a for a in args.split(",") if a.strip()])
+            assert n == len(_lib.SIGNATURES[name]), (name, n, len(_lib.SIGNATURES[name]))
+
+
+def test_pack_roundtrip_and_layout():
+    from llamagen_amd.engine import pack_act, pack_weight, unpack_act
+    for dt, epl in ((torch.bfloat16, 8), (torch.float32, 4)):
+        kc = 4 * epl
+        x = torch.randn(37, 4 * kc).to(dt)
+        xp = pack_act(x, 4)
+        assert xp.shape == (4, 4, 4, 16, epl)
+        assert torch.equal(unpack_act(xp, 37), x)
+        # element (m, k) lives at [k/KC][m/16][(k%KC)/EPL][m%16][k%EPL]
+        m, k = 21, kc + 2 * epl + 1
+        assert xp[k // kc, m // 16, (k % kc) // epl, m % 16, k % epl] == x[m, k]
+        w = torch.randn(48, 2 * kc).to(dt)
+        wp = pack_weight(w)
+        n = 35
+        assert wp[n // 16, k // kc, (k % kc) // epl, n % 16, k % epl] == w[n, k]
+
+
+def test_registries_and_missing_gpu_is_loud():
+    from llamagen_amd import GPT_models, VQ_models, generate
+    assert set(GPT_models) == {"GPT-B", "GPT-L", "GPT-XL", "GPT-XXL", "GPT-XXXL", "GPT-1B", "GPT-3B", "GPT-7B"}
+    assert set(VQ_models) == {"VQ-16", "VQ-8"}
+    from llamagen_amd.gpt import ModelArgs, Transformer
+    m = Transformer(ModelArgs(n_layer=1, n_head=2, dim=64, vocab_size=64, block_size=4, num_classes=3))
+    assert (m.output.weight == 0).all()  # gpt.py:305
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):  # no silent CPU fallback
+            generate(m, torch.tensor([0]), 4)
+        vq = VQ_models["VQ-16"]()
+        with pytest.raises(RuntimeError):
+            vq.decode_code(torch.zeros(1, 4, dtype=torch.long), [1, 8, 2, 2])

@@ -1,0 +1,293 @@
+"""GPU parity tests of the GPT decode path: every HIP kernel against the CPU oracle on the same
+seeded inputs, then whole generate() runs against the reference-made goldens.  All calls go through
+the C ABI (ctypes) exactly like the product does."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import llamagen_oracle as O  # noqa: E402
+from tests.cases import GPT_CASES, make_gpt_inputs, noise_stream  # noqa: E402
+from tests.util import DT, build_gpt_holder, load_golden, oracle_cfg  # noqa: E402
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a real MI355X"
+    return torch.device("cuda:0")
+
+
+def _L():
+    from llamagen_amd import _lib
+    return _lib
+
+
+def _close(got, ref, dt, what, frac_ulp1=0.02):
+    """fp32: tight absolute/relative; bf16: identical up to rare 1-ulp flips from accumulation order."""
+    got, ref = got.float().cpu(), ref.float().cpu()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    err = (got - ref).abs()
+    scale = ref.abs().max().item() + 1e-30
+    if dt == torch.float32:
+        assert err.max().item() <= 2e-5 * max(1.0, scale), (what, err.max().item(), scale)
+    else:
+        ulp = torch.maximum(ref.abs(), got.abs()) * 2.0 ** -7 + 1e-30  # >= 1 bf16 ulp of the value
+        bad = err > ulp * 1.01
+        assert not bad.any(), (what, "errors beyond 1 bf16 ulp", int(bad.sum()), err.max().item())
+        assert (err > 0).float().mean().item() <= frac_ulp1, (what, "too many 1-ulp flips", (err > 0).float().mean().item())
+
+
+def _rand(shape, dt, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dt)
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("M,d", [(1, 256), (3, 800), (64, 1024), (40, 3200)])
+def test_rmsnorm(dt, M, d):
+    from llamagen_amd.engine import pack_act, unpack_act
+    L, dev = _L(), _dev()
+    x, w = _rand((M, d), dt, 1), (1 + 0.1 * _rand((d,), torch.float32, 2)).to(dt)
+    mts = (M + 15) // 16
+    xp = pack_act(x.to(dev), mts)
+    out = torch.zeros_like(xp)
+    L.check(L.lib().lgen_rmsnorm(L.ptr(xp), L.ptr(w.to(dev)), L.ptr(out), mts, d, 1e-5,
+                                 L.BF16 if dt == torch.bfloat16 else L.F32, L.stream()), "rmsnorm")
+    ref = O.rms_norm(x.float(), w, 1e-5, dt)
+    _close(unpack_act(out, M), ref, dt, "rmsnorm")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("M,N,K,tiles", [
+    (1, 768, 256, (1, 1, 1)), (5, 1024, 512, (1, 2, 4)), (64, 3072, 1024, (4, 1, 8)), (64, 1024, 2816, (4, 1, 8)),
+    (64, 2048, 1024, (4, 4, 2)), (33, 512, 800, (4, 2, 3)), (128, 512, 1024, (8, 2, 4)), (128, 512, 1024, (8, 1, 8)),
+    (256, 256, 512, (8, 1, 2)),
+])
+def test_gemm_rows_packed_res(dt, M, N, K, tiles):
+    from llamagen_amd.engine import pack_act, pack_weight, unpack_act
+    L, dev = _L(), _dev()
+    code = L.BF16 if dt == torch.bfloat16 else L.F32
+    if dt == torch.float32 and K % 16:
+        pytest.skip("K")
+    x, w = _rand((M, K), dt, 3), _rand((N, K), dt, 4, 0.05)
+    mts = (M + 15) // 16
+    mts = {3: 4}.get(mts, mts)
+    if mts > 4:
+        mts = (mts + 7) // 8 * 8
+    mt, nt, kw = tiles
+    mt = min(mt, mts)
+    xp, wp = pack_act(x.to(dev), mts), pack_weight(w.to(dev))
+    ref = O.linear(x.float(), w.float(), dt)
+    rows = torch.zeros(mts * 16, N, dtype=dt, device=dev)
+    L.check(L.lib().lgen_gemm(L.ptr(wp), L.ptr(xp), L.ptr(rows), M, mts, N, K, L.EPI_ROWS, code, mt, nt, kw, L.stream()), "gemm rows")
+    _close(rows[:M], ref, dt, "gemm rows")
+    kc = 32 if dt == torch.bfloat16 else 16
+    if N % kc == 0:
+        pk = torch.zeros(N // kc, mts, 64, kc // 4, dtype=dt, device=dev)
+        L.check(L.lib().lgen_gemm(L.ptr(wp), L.ptr(xp), L.ptr(pk), M, mts, N, K, L.EPI_PACKED, code, mt, nt, kw, L.stream()), "gemm packed")
+        _close(unpack_act(pk, M), ref, dt, "gemm packed")
+        h0 = _rand((M, N), dt, 5)
+        hp = pack_act(h0.to(dev), mts)
+        L.check(L.lib().lgen_gemm(L.ptr(wp), L.ptr(xp), L.ptr(hp), M, mts, N, K, L.EPI_RES, code, mt, nt, kw, L.stream()), "gemm res")
+        _close(unpack_act(hp, M), O._rnd(h0.float() + ref, dt), dt, "gemm res")
+        L.check(L.lib().lgen_gemm(L.ptr(wp), L.ptr(xp), L.ptr(pk), M, mts, N, K, L.EPI_GELU, code, mt, nt, kw, L.stream()), "gemm gelu")
+        _close(unpack_act(pk, M), O._rnd(O.gelu_tanh(ref), dt), dt, "gemm gelu", frac_ulp1=0.05)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("M,F,K,tiles", [(2, 512, 256, (1, 2, 2)), (64, 2816, 1024, (4, 2, 8)), (20, 2304, 800, (2, 4, 1))])
+def test_gemm_swiglu(dt, M, F, K, tiles):
+    from llamagen_amd.engine import pack_act, pack_weight, unpack_act
+    L, dev = _L(), _dev()
+    code = L.BF16 if dt == torch.bfloat16 else L.F32
+    x, w1, w3 = _rand((M, K), dt, 6), _rand((F, K), dt, 7, 0.05), _rand((F, K), dt, 8, 0.05)
+    mts = (M + 15) // 16
+    mt, nt, kw = tiles
+    mt = min(mt, mts)
+    w13 = torch.stack([pack_weight(w1.to(dev)), pack_weight(w3.to(dev))], dim=1).flatten(0, 1).contiguous()
+    kc = 32 if dt == torch.bfloat16 else 16
+    out = torch.zeros(F // kc, mts, 64, kc // 4, dtype=dt, device=dev)
+    L.check(L.lib().lgen_gemm(L.ptr(w13), L.ptr(pack_act(x.to(dev), mts)), L.ptr(out), M, mts, 2 * F, K, L.EPI_SWIGLU,
+                              code, mt, nt, kw, L.stream()), "gemm swiglu")
+    a1, a3 = O.linear(x.float(), w1.float(), dt), O.linear(x.float(), w3.float(), dt)
+    ref = O._rnd(O._rnd(torch.nn.functional.silu(a1), dt) * a3, dt)
+    _close(unpack_act(out, M), ref, dt, "swiglu", frac_ulp1=0.05)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("B2,H,hd,grid,pos", [(2, 4, 64, 4, 0), (2, 4, 64, 4, 7), (33, 16, 64, 24, 300), (3, 8, 100, 4, 16)])
+def test_qkv_rope_append_and_attention(dt, B2, H, hd, grid, pos):
+    """wqkv GEMM + RoPE + cache append, then decode attention over the cache, vs the oracle."""
+    from llamagen_amd.engine import pack_act, pack_weight, precompute_freqs_cis_2d, unpack_act
+    L, dev = _L(), _dev()
+    code = L.BF16 if dt == torch.bfloat16 else L.F32
+    d = H * hd
+    hdp = 64 if hd <= 64 else 128
+    S8 = O.find_multiple(1 + grid * grid, 8)
+    x, w = _rand((B2, d), dt, 9), _rand((3 * d, d), dt, 10, 0.05)
+    freqs = precompute_freqs_cis_2d(grid, hd, 10000.0, 1)
+    assert torch.equal(freqs, O.precompute_freqs_cis_2d(grid, hd, 10000.0, 1))
+    kcache = _rand((B2, H, S8, hd), dt, 11)
+    vcache = _rand((B2, H, S8, hd), dt, 12)
+    mts = (B2 + 15) // 16
+    mts = {3: 4}.get(mts, mts)
+    kc_d = torch.zeros(B2, H, S8, hdp, dtype=dt, device=dev)
+    vc_d = torch.zeros(B2, H, S8, hdp, dtype=dt, device=dev)
+    kc_d[..., :hd] = kcache.to(dev)
+    vc_d[..., :hd] = vcache.to(dev)
+    q_d = torch.zeros(mts * 16, H, hdp, dtype=dt, device=dev)
+    state = torch.tensor([pos, 0], dtype=torch.int32, device=dev)
+    L.check(L.lib().lgen_gemm_qkv_rope(L.ptr(pack_weight(w.to(dev))), L.ptr(pack_act(x.to(dev), mts)), L.ptr(q_d), L.ptr(kc_d),
+                                       L.ptr(vc_d), L.ptr(freqs.to(dev)), L.ptr(state), B2, mts, d, H, hd, hdp, S8, code,
+                                       min(mts, 4), 1, 4, L.stream()), "qkv")
+    qkv = O.linear(x.float(), w.float(), dt)
+    xq, xk, xv = qkv.split([d, d, d], dim=-1)
+    fr = freqs[pos:pos + 1]
+    xq = O.apply_rotary_emb(xq.reshape(B2, 1, H, hd), fr, dt)
+    xk = O.apply_rotary_emb(xk.reshape(B2, 1, H, hd), fr, dt)
+    _close(q_d[:B2, :, :hd], xq[:, 0], dt, "q rope")
+    kref, vref = kcache.float().clone(), vcache.float().clone()
+    kref[:, :, pos] = xk[:, 0]
+    vref[:, :, pos] = xv.reshape(B2, H, hd)
+    _close(kc_d[..., :hd], kref, dt, "k cache")
+    _close(vc_d[..., :hd], vref, dt, "v cache")
+    assert (kc_d[..., hd:] == 0).all() and (q_d[:, :, hd:] == 0).all()
+    # attention over the (oracle-exact) cache contents so that errors do not compound
+    kc_d[..., :hd] = kref.to(dt).to(dev)
+    vc_d[..., :hd] = vref.to(dt).to(dev)
+    q_d[:B2, :, :hd] = xq[:, 0].to(dt).to(dev)
+    kcd = 32 if dt == torch.bfloat16 else 16
+    for use_mask in (False, True):
+        mask = torch.tril(torch.ones(S8, S8, dtype=torch.bool)).unsqueeze(0).repeat(B2, 1, 1)
+        if use_mask:
+            g = torch.Generator().manual_seed(13)
+            mask &= torch.rand(B2, 1, S8, generator=g) > 0.3
+            mask |= torch.eye(S8, dtype=torch.bool)
+        out = torch.zeros(d // kcd, mts, 64, kcd // 4, dtype=dt, device=dev)
+        md = mask.to(dev).contiguous() if use_mask else None
+        L.check(L.lib().lgen_attn_decode(L.ptr(q_d), L.ptr(kc_d), L.ptr(vc_d), L.ptr(out), L.ptr(state), L.ptr(md), B2, mts, H,
+                                         hd, hdp, S8, code, L.stream()), "attn")
+        ref = O.sdpa_math(xq.transpose(1, 2), kref, vref, mask[:, None, pos:pos + 1], dt)  # [B,H,1,hd]
+        _close(unpack_act(out, B2), ref.transpose(1, 2).reshape(B2, d), dt, f"attn mask={use_mask}")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("B,V,cfg,interval,step,temp,topk,greedy", [
+    (3, 1024, 4.0, -1, 0, 1.0, 100, 0), (32, 16384, 4.0, -1, 5, 1.0, 2000, 0), (5, 2048, 1.0, -1, 3, 0.8, 0, 0),
+    (4, 1024, 3.0, 2, 4, 1.0, 50, 0), (4, 1024, 3.0, 2, 3, 1.0, 50, 0), (2, 16384, 1.5, -1, 1, 1.0, 1, 0),
+    (3, 1024, 4.0, -1, 2, 1.0, 100, 1), (2, 1024, 2.0, -1, 2, 1.0, 5000, 0),
+])
+def test_sampler_index_exact(dt, B, V, cfg, interval, step, temp, topk, greedy):
+    L, dev = _L(), _dev()
+    code = L.BF16 if dt == torch.bfloat16 else L.F32
+    use_cfg = cfg > 1.0
+    B2 = 2 * B if use_cfg else B
+    logits = _rand((B2, V), dt, 20 + step, 2.0)
+    if dt == torch.bfloat16:
+        logits[:, 7] = logits[:, 3]  # exact ties around
+    g = torch.Generator().manual_seed(99)
+    noise = torch.empty(B, V).exponential_(1, generator=g)
+    cur = torch.zeros(B2, dtype=torch.int32, device=dev)
+    seq = torch.full((B, 16), -1, dtype=torch.int32, device=dev)
+    state = torch.tensor([10 + step, step], dtype=torch.int32, device=dev)
+    L.check(L.lib().lgen_sample(L.ptr(logits.to(dev)), L.ptr(noise.to(dev)), L.ptr(cur), L.ptr(seq), L.ptr(state), B, V, 16,
+                                1 if use_cfg else 0, cfg, interval, temp, topk, 1.0, greedy, 1, code, L.stream()), "sample")
+    flag = not (step > 0 and interval > -1 and (step - 1) > interval)
+    mixed = O.cfg_mix(logits.float(), cfg, flag)
+    idx, _ = O.sample(mixed, temperature=temp, top_k=topk, top_p=1.0, sample_logits=not greedy, noise=noise)
+    assert seq[:, step].cpu().tolist() == idx.view(-1).tolist()
+    assert cur[:B].cpu().tolist() == idx.view(-1).tolist()
+    if use_cfg:
+        assert cur[B:].cpu().tolist() == idx.view(-1).tolist()
+    assert state.cpu().tolist() == [11 + step, step + 1]
+    assert (seq[:, :step] == -1).all() and (seq[:, step + 1:] == -1).all()
+
+
+# ------------------------------------------------------------------------------------------------
+def _hip_model(case):
+    m, sd = build_gpt_holder(case)
+    return m.to(device=_dev(), dtype=DT[case["dtype"]]), sd
+
+
+def _noise_seq(case):
+    fn = noise_stream(case["rseed"])
+    V = case["kwargs"]["vocab_size"]
+    return torch.stack([fn((case["batch"], V)) for _ in range(case["n_new"])])
+
+
+HIP_FP32 = [k for k, c in GPT_CASES.items() if c["dtype"] == "fp32" and c["top_p"] >= 1.0]
+
+
+@pytest.mark.parametrize("name", HIP_FP32)
+def test_generate_tokens_match_reference_golden_fp32(name):
+    """fp32 free-running generate() on the HIP engine, fed the reference's CPU noise stream, must
+    reproduce the reference's token ids bit-exactly (goldens made by the reference itself)."""
+    from llamagen_amd import generate
+    case = GPT_CASES[name]
+    gold = load_golden("gpt_" + name)
+    m, _ = _hip_model(case)
+    cond, masks = make_gpt_inputs(case)
+    dev = _dev()
+    toks = generate(m, cond.to(dev), case["n_new"], emb_masks=None if masks is None else masks.to(dev),
+                    cfg_scale=case["cfg_scale"], cfg_interval=case["cfg_interval"], temperature=case["temperature"],
+                    top_k=case["top_k"], top_p=case["top_p"], sample_logits=case["sample_logits"],
+                    _noise_seq=_noise_seq(case) if case["sample_logits"] else None)
+    assert toks.dtype == torch.int32 and toks.device.type == "cuda"
+    np.testing.assert_array_equal(toks.cpu().numpy(), gold["tokens"])
+
+
+@pytest.mark.parametrize("name", [k for k, c in GPT_CASES.items() if c["dtype"] == "bf16"])
+def test_forward_teacher_forced_bf16(name):
+    """bf16: feed the reference's tokens through Transformer.__call__ (the drop-in forward API) and
+    hold every step's CFG-mixed logits to bf16 resolution of the reference's logits."""
+    case = GPT_CASES[name]
+    gold = load_golden("gpt_" + name)
+    m, _ = _hip_model(case)
+    dev = _dev()
+    cond, _ = make_gpt_inputs(case)
+    B = case["batch"]
+    cond_c = torch.cat([cond, torch.ones_like(cond) * m.num_classes]).to(dev)
+    m.setup_caches(2 * B, 1 + case["n_new"], torch.bfloat16)
+    toks = torch.from_numpy(gold["tokens"]).to(dev)
+    got = []
+    lg, _ = m(None, cond_c, torch.arange(0, 1, device=dev))
+    got.append(O.cfg_mix(lg[:, -1].cpu(), case["cfg_scale"]))
+    for i in range(case["n_new"] - 1):
+        x = torch.cat([toks[:, i:i + 1], toks[:, i:i + 1]])
+        lg, _ = m(x, None, torch.tensor([1 + i], device=dev, dtype=torch.int))
+        got.append(O.cfg_mix(lg[:, -1].cpu(), case["cfg_scale"]))
+    ref = gold["trace_logits"]
+    got = np.stack([got[int(s)].numpy() for s in gold["trace_steps"]])
+    ulp = np.abs(ref).max() * 2.0 ** -8
+    err = np.abs(got - ref)
+    assert err.max() <= 4 * ulp, (err.max(), ulp)
+    assert err.mean() <= 0.25 * ulp, (err.mean(), ulp)
+
+
+@pytest.mark.parametrize("name", ["tiny_cfg4", "hd100_cfg4", "tiny_nocfg_temp", "tiny_interval"])
+def test_generate_graph_replay_matches_oracle_on_gpu_noise(name):
+    """The production path (hipGraph replay, noise drawn on the GPU by torch's default generator):
+    (a) replayed noise == eager noise of the same seed, (b) tokens == oracle fed that noise."""
+    from llamagen_amd import generate
+    case = dict(GPT_CASES[name])
+    case["n_new"] = 12
+    m, sd = _hip_model(case)
+    dev = _dev()
+    cond, masks = make_gpt_inputs(case)
+    kw = dict(cfg_scale=case["cfg_scale"], cfg_interval=case["cfg_interval"], temperature=case["temperature"],
+              top_k=case["top_k"], top_p=case["top_p"], sample_logits=True)
+    torch.manual_seed(1234)
+    t1 = generate(m, cond.to(dev), case["n_new"], **kw)
+    torch.manual_seed(1234)
+    t2 = generate(m, cond.to(dev), case["n_new"], **kw)
+    assert torch.equal(t1, t2)
+    torch.manual_seed(1234)
+    V = case["kwargs"]["vocab_size"]
+    qs = [torch.empty(case["batch"], V, device=dev).exponential_(1).cpu() for _ in range(case["n_new"])]
+    it = iter(qs)
+    model = O.GPTOracle(oracle_cfg(case), sd, torch.float32)
+    ref = O.generate(model, cond, case["n_new"], emb_masks=masks, noise_fn=lambda shape: next(it), **kw)
+    np.testing.assert_array_equal(t1.cpu().numpy(), ref.numpy())

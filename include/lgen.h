@@ -77,6 +77,47 @@ int lgen_sample(const void* logits, const float* noise, int* cur_tok, int* seq, 
 
 int lgen_advance_state(int* state, void* stream);
 
+/* ---- VQ-VAE tokenizer (tokenizer/tokenizer_image/vq_model.py), fp32 NHWC activations ------------- */
+
+/* F.normalize(embedding.weight) (vq_model.py:223,264) + |e|^2 per row; cb_norm [n_e][dim], e_sq [n_e]. */
+int lgen_vq_codebook_prep(const float* codebook, float* cb_norm, float* e_sq, int n_e, int dim, int l2norm,
+                          void* stream);
+
+/* VectorQuantizer.get_codebook_entry (vq_model.py:261-276) + post_quant_conv 1x1 (vq_model.py:48):
+ * indices int64 [npix] -> out NHWC [npix][cout]; w [cout][dim], bias [cout]. */
+int lgen_vq_lookup_pqconv(const float* cb_norm, const long long* indices, const float* w, const float* bias,
+                          float* out_nhwc, int npix, int n_e, int dim, int cout, void* stream);
+
+/* VectorQuantizer.forward eval path (vq_model.py:215-232): z NCHW [B][dim][hw] -> int64 [B*hw] nearest
+ * entry (first index wins ties); never materialises the [N][n_e] distance matrix. */
+int lgen_vq_argmin(const float* z_nchw, const float* cb_norm, const float* e_sq, long long* indices, int nvec, int hw,
+                   int n_e, int dim, int l2norm, void* stream);
+
+/* nn.GroupNorm(32, C, eps) statistics (vq_model.py:359-362): stats [B][32][2] = (mean, rstd);
+ * partial_ws: B*nchunk*64 doubles. */
+int lgen_gn_stats(const float* x_nhwc, double* partial_ws, float* stats, int B, int hw, int C, float eps, int nchunk,
+                  void* stream);
+
+/* mode bit0: apply GroupNorm (stats/gamma/beta), bit1: swish x*sigmoid(x) (vq_model.py:354-356);
+ * writes x as (hi, lo) bf16 planes with the same NHWC indexing. */
+int lgen_gn_swish_split(const float* x_nhwc, const float* stats, const float* gamma, const float* beta, void* hi,
+                        void* lo, int B, int hw, int C, int mode, void* stream);
+
+/* x [B][R][C] fp32 -> (hi, lo) bf16 [B][C][ldr] (transposed, zero padded to ldr >= R). */
+int lgen_split_t(const float* x, void* hi, void* lo, int B, int R, int C, int ldr, void* stream);
+
+/* F.softmax(dim=-1) of AttnBlock (vq_model.py:341) on [rows][n] fp32 -> (hi, lo) bf16 [rows][ldo]. */
+int lgen_softmax_split(const float* scores, void* hi, void* lo, int rows, int n, int ldo, void* stream);
+
+/* nn.Conv2d 3x3 (pad 1) / 1x1, stride 1 (vq_model.py:288-291,321-324) as implicit GEMM on MFMA with
+ * hi/lo-split bf16 operands (3 passes, fp32 accumulate); optional nearest-2x upsample of the input
+ * (Upsample, vq_model.py:374-378: a_* is then [B][H/2][W/2][Cin]), bias, residual add (NHWC like out),
+ * NCHW output, scale alpha.  With ksize 1 and w_bstride != 0 it is a batched NT GEMM (torch.bmm of
+ * AttnBlock, vq_model.py:337,346).  w_* planes: [taps][Npad][Cin] bf16. */
+int lgen_conv_igemm(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo, const float* bias,
+                    const float* res, float* out, int B, int H, int W, int Cin, int Cout, int Npad, int ksize,
+                    int upsample, int out_nchw, long long w_bstride, float alpha, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

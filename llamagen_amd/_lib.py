@@ -32,6 +32,14 @@ SIGNATURES = {
     "lgen_attn_decode": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "lgen_sample": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _F, _I, _F, _I, _I, _I, _P],
     "lgen_advance_state": [_P, _P],
+    "lgen_vq_codebook_prep": [_P, _P, _P, _I, _I, _I, _P],
+    "lgen_vq_lookup_pqconv": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "lgen_vq_argmin": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "lgen_gn_stats": [_P, _P, _P, _I, _I, _I, _F, _I, _P],
+    "lgen_gn_swish_split": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "lgen_split_t": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "lgen_softmax_split": [_P, _P, _P, _I, _I, _I, _P],
+    "lgen_conv_igemm": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _c.c_longlong, _F, _P],
 }
 
 _lib = None

@@ -1,0 +1,223 @@
+// Implicit-GEMM convolution / batched NT-GEMM on MFMA with hi/lo-split bf16 operands.
+//
+// Replaces, in the VQ decoder (tokenizer/tokenizer_image/vq_model.py): nn.Conv2d 3x3 / 1x1
+// (:288-291, 321-324, 134, 167), F.interpolate(nearest, 2x) + conv (:374-378, folded into the
+// input indexing), the residual add of ResnetBlock / AttnBlock (:314, 351, fused epilogue) and
+// the two torch.bmm of AttnBlock (:337, 346).
+//
+//   out[b][p][n] = alpha * sum_{tap, c} A[b][p + tap][c] * W[tap][n][c]  (+ bias[n]) (+ res[b][p][n])
+//
+// A and W arrive as (hi, lo) bf16 plane pairs (x = hi + lo); each product is accumulated as
+// hi*hi + hi*lo + lo*hi with `v_mfma_f32_16x16x32_bf16` into fp32 (the lo*lo term, < 2^-16
+// relative, is dropped): 3 MFMA passes at the bf16 rate (2.5 PF/3) instead of fp32 MFMA (157 TF).
+//
+// Tiling: workgroup = 4 waves, BM = WMW*JM*16 pixels x BN = WNW*JN*16 output channels, K-step =
+// one tap x 32 input channels.  The pixel tile is 128 consecutive NHWC pixels of one image; the
+// nine taps re-read shifted rows through L2.  Global -> registers -> LDS double buffer (loads for
+// step s+1 are issued before the MFMAs of step s, written after them; one barrier per step).  LDS
+// tiles are [rows][32] bf16 with a 16-byte-slot XOR swizzle that makes both the staging
+// `ds_write_b128` and the fragment `ds_read_b128` conflict-free for the 16x16x32 operand layout.
+// The weight tile is the MFMA A operand and the pixel tile the B operand, so a lane ends up with
+// 4 consecutive output channels of one pixel: 16-byte NHWC stores.
+#include "lgen_common.h"
+#include "../../include/lgen.h"
+
+struct IgemmArgs {
+    const uint16_t* a_hi; const uint16_t* a_lo;  // [B][Hs][Ws][Cin]
+    const uint16_t* w_hi; const uint16_t* w_lo;  // [taps][Npad][Cin]
+    const float* bias;   // [Cout] or null
+    const float* res;    // like out (NHWC) or null
+    float* out;
+    int H, W, Cin, Cout, Npad, ks, ups, out_nchw;
+    long long a_bstride, w_bstride, o_bstride;
+    float alpha;
+};
+
+LGEN_DEV int swz(int row, int seg) { return row * 64 + ((seg ^ ((row >> 2) & 2)) << 4); }  // byte offset in a [rows][32]bf16 tile
+
+template <int JN, int JM, int WNW>
+__global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
+    constexpr int WMW = 4 / WNW;
+    constexpr int BM = WMW * JM * 16, BN = WNW * JN * 16;
+    constexpr int A_IT = (BM * 4 + 255) / 256, B_IT = (BN * 4 + 255) / 256;
+    constexpr int STAGE = (BM + BN) * 64 * 2;  // bytes: (pixel tile + weight tile) x (hi, lo)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wn = wv % WNW, wm = wv / WNW;
+    const int b = blockIdx.z;
+    const int p0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int HW = a.H * a.W;
+    const int Hs = a.H >> a.ups, Ws = a.W >> a.ups;
+    const uint16_t* ahi = a.a_hi + (size_t)b * a.a_bstride;
+    const uint16_t* alo = a.a_lo + (size_t)b * a.a_bstride;
+    const uint16_t* whi = a.w_hi + (size_t)b * a.w_bstride;
+    const uint16_t* wlo = a.w_lo + (size_t)b * a.w_bstride;
+
+    // per-thread staging coordinates
+    int apy[A_IT], apx[A_IT];
+    bool apv[A_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int idx = t + i * 256;
+        const int p = p0 + (idx >> 2);
+        apv[i] = (idx < BM * 4) && p < HW;
+        apy[i] = p / a.W;
+        apx[i] = p - apy[i] * a.W;
+    }
+    const int kchunks = a.Cin >> 5;
+    const int taps = a.ks * a.ks;
+    const int nsteps = taps * kchunks;
+    const int pad = a.ks >> 1;
+
+    uint4 ra_hi[A_IT], ra_lo[A_IT], rb_hi[B_IT], rb_lo[B_IT];
+    auto gload = [&](int step) {
+        const int tap = step / kchunks, kc = step - tap * kchunks;
+        const int dy = tap / a.ks - pad, dx = tap % a.ks - pad;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int idx = t + i * 256;
+            int sy = apy[i] + dy, sx = apx[i] + dx;
+            const bool ok = apv[i] && sy >= 0 && sy < a.H && sx >= 0 && sx < a.W;
+            sy >>= a.ups; sx >>= a.ups;
+            const size_t off = (((size_t)sy * Ws + sx) * a.Cin + kc * 32 + (idx & 3) * 8);
+            ra_hi[i] = ok ? *(const uint4*)(ahi + off) : make_uint4(0, 0, 0, 0);
+            ra_lo[i] = ok ? *(const uint4*)(alo + off) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            const int idx = t + i * 256;
+            if (idx < BN * 4) {
+                const size_t off = (((size_t)tap * a.Npad + n0 + (idx >> 2)) * a.Cin + kc * 32 + (idx & 3) * 8);
+                rb_hi[i] = *(const uint4*)(whi + off);
+                rb_lo[i] = *(const uint4*)(wlo + off);
+            }
+        }
+    };
+    auto lstore = [&](int buf) {
+        unsigned char* base = smem + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int idx = t + i * 256;
+            if (idx < BM * 4) {
+                const int o = swz(idx >> 2, idx & 3);
+                *(uint4*)(base + o) = ra_hi[i];
+                *(uint4*)(base + BM * 64 + o) = ra_lo[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            const int idx = t + i * 256;
+            if (idx < BN * 4) {
+                const int o = swz(idx >> 2, idx & 3);
+                *(uint4*)(base + BM * 128 + o) = rb_hi[i];
+                *(uint4*)(base + BM * 128 + BN * 64 + o) = rb_lo[i];
+            }
+        }
+    };
+
+    f32x4_t acc[JN][JM];
+#pragma unroll
+    for (int j = 0; j < JN; ++j)
+#pragma unroll
+        for (int i = 0; i < JM; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    const int fr = lane & 15, fg = lane >> 4;
+    for (int step = 0; step < nsteps; ++step) {
+        const int buf = step & 1;
+        if (step + 1 < nsteps) gload(step + 1);
+        const unsigned char* base = smem + buf * STAGE;
+        uint4 phi[JM], plo[JM], whi_f[JN], wlo_f[JN];
+#pragma unroll
+        for (int i = 0; i < JM; ++i) {
+            const int o = swz((wm * JM + i) * 16 + fr, fg);
+            phi[i] = *(const uint4*)(base + o);
+            plo[i] = *(const uint4*)(base + BM * 64 + o);
+        }
+#pragma unroll
+        for (int j = 0; j < JN; ++j) {
+            const int o = swz((wn * JN + j) * 16 + fr, fg);
+            whi_f[j] = *(const uint4*)(base + BM * 128 + o);
+            wlo_f[j] = *(const uint4*)(base + BM * 128 + BN * 64 + o);
+        }
+#pragma unroll
+        for (int j = 0; j < JN; ++j)
+#pragma unroll
+            for (int i = 0; i < JM; ++i) {
+                acc[j][i] = BF16::mma(wlo_f[j], phi[i], acc[j][i]);
+                acc[j][i] = BF16::mma(whi_f[j], plo[i], acc[j][i]);
+                acc[j][i] = BF16::mma(whi_f[j], phi[i], acc[j][i]);
+            }
+        if (step + 1 < nsteps) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: lane holds out channels n = nb + fg*4 + {0..3} of pixel p = pb + fr
+    float* outb = a.out + (size_t)b * a.o_bstride;
+    const float* resb = a.res ? a.res + (size_t)b * a.o_bstride : nullptr;
+#pragma unroll
+    for (int j = 0; j < JN; ++j) {
+        const int n = n0 + (wn * JN + j) * 16 + fg * 4;
+#pragma unroll
+        for (int i = 0; i < JM; ++i) {
+            const int p = p0 + (wm * JM + i) * 16 + fr;
+            if (p >= HW || n >= a.Cout) continue;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = acc[j][i][e] * a.alpha;
+                if (a.bias && n + e < a.Cout) v[e] += a.bias[n + e];
+            }
+            if (!a.out_nchw && n + 3 < a.Cout && (a.Cout & 3) == 0) {
+                const size_t o = (size_t)p * a.Cout + n;
+                if (resb) {
+                    const float4 r = *(const float4*)(resb + o);
+                    v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+                }
+                *(float4*)(outb + o) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (n + e >= a.Cout) continue;
+                    const size_t o = a.out_nchw ? (size_t)(n + e) * HW + p : (size_t)p * a.Cout + n + e;
+                    outb[o] = v[e] + (resb ? resb[o] : 0.f);
+                }
+            }
+        }
+    }
+}
+
+template <int JN, int JM, int WNW>
+static int launch_igemm(const IgemmArgs& a, int B, hipStream_t st) {
+    constexpr int BM = (4 / WNW) * JM * 16, BN = WNW * JN * 16;
+    const size_t lds = 2 * (size_t)(BM + BN) * 64 * 2;
+    if (a.Npad % BN) return LGEN_ERR_BAD_ARG;
+    static bool attr = false;
+    if (!attr && lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<JN, JM, WNW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    dim3 grid((a.H * a.W + BM - 1) / BM, a.Npad / BN, B);
+    hipLaunchKernelGGL((igemm_kernel<JN, JM, WNW>), grid, dim3(256), lds, st, a);
+    LGEN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int lgen_conv_igemm(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo, const float* bias,
+                               const float* res, float* out, int B, int H, int W, int Cin, int Cout, int Npad, int ksize,
+                               int upsample, int out_nchw, long long w_bstride, float alpha, void* stream) {
+    if (Cin % 32 || (ksize != 1 && ksize != 3) || Npad % 16 || Npad < Cout || (upsample && ((H | W) & 1)))
+        return LGEN_ERR_BAD_ARG;
+    if (B == 0 || H * W == 0) return 0;
+    IgemmArgs a{(const uint16_t*)a_hi, (const uint16_t*)a_lo, (const uint16_t*)w_hi, (const uint16_t*)w_lo, bias, res, out,
+                H, W, Cin, Cout, Npad, ksize, upsample ? 1 : 0, out_nchw,
+                (long long)(H >> (upsample ? 1 : 0)) * (W >> (upsample ? 1 : 0)) * Cin, w_bstride, (long long)H * W * Cout, alpha};
+    hipStream_t st = (hipStream_t)stream;
+    if (Npad % 128 == 0) return launch_igemm<4, 4, 2>(a, B, st);   // 128 px x 128 ch
+    if (Npad % 64 == 0) return launch_igemm<4, 2, 1>(a, B, st);    // 128 px x 64 ch
+    return launch_igemm<1, 2, 1>(a, B, st);                        // 128 px x 16 ch (conv_out, Cout = 3)
+}

@@ -43,6 +43,8 @@ def pack_act(x: torch.Tensor, mts: int) -> torch.Tensor:
 
 def unpack_act(xp: torch.Tensor, M: int) -> torch.Tensor:
     """Inverse of pack_act: XP[K/KC][MTs][4][16][EPL] -> [M, K]."""
+    if xp.dim() == 4:  # [K/KC][MTs][64][EPL] workspace view
+        xp = xp.view(xp.shape[0], xp.shape[1], 4, 16, xp.shape[3])
     kch, mts, g, r, epl = xp.shape
     return xp.permute(1, 3, 0, 2, 4).reshape(mts * 16, kch * g * epl)[:M].contiguous()
 
@@ -264,7 +266,7 @@ class DecodeEngine:
             emb = self.caption_embed(cond_combined)
             for t in range(T):  # causal prefix, one position at a time (same math as the batched prefill)
                 self.state[0] = t
-                self.hp.copy_(pack_act(emb[:, t].contiguous(), self.MTs))
+                self.hp.copy_(pack_act(emb[:, t].contiguous(), self.MTs).view_as(self.hp))
                 self._layers_and_logits(want_logits=(t == T - 1))
         self._sample(B, sp)  # -> state = [T, 1]
         # ---- decode (generate.py:105-123)
@@ -314,7 +316,7 @@ class DecodeEngine:
         for j, p in enumerate(pos):
             self.state[0] = p
             if embs is not None:
-                self.hp.copy_(pack_act(embs[:, j].contiguous(), self.MTs))
+                self.hp.copy_(pack_act(embs[:, j].contiguous(), self.MTs).view_as(self.hp))
             elif cond_idx is not None:
                 self._embed(self.cls_emb, rows)
             else:

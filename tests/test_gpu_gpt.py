@@ -33,7 +33,8 @@ def _close(got, ref, dt, what, frac_ulp1=0.02):
     if dt == torch.float32:
         assert err.max().item() <= 2e-5 * max(1.0, scale), (what, err.max().item(), scale)
     else:
-        ulp = torch.maximum(ref.abs(), got.abs()) * 2.0 ** -7 + 1e-30  # >= 1 bf16 ulp of the value
+        # >= 1 bf16 ulp of the value, floored by fp32 accumulation noise on cancelling sums
+        ulp = torch.maximum(ref.abs(), got.abs()) * 2.0 ** -7 + 2e-5 * scale
         bad = err > ulp * 1.01
         assert not bad.any(), (what, "errors beyond 1 bf16 ulp", int(bad.sum()), err.max().item())
         assert (err > 0).float().mean().item() <= frac_ulp1, (what, "too many 1-ulp flips", (err > 0).float().mean().item())
@@ -54,7 +55,8 @@ def test_rmsnorm(dt, M, d):
     mts = (M + 15) // 16
     xp = pack_act(x.to(dev), mts)
     out = torch.zeros_like(xp)
-    L.check(L.lib().lgen_rmsnorm(L.ptr(xp), L.ptr(w.to(dev)), L.ptr(out), mts, d, 1e-5,
+    w_d = w.to(dev)
+    L.check(L.lib().lgen_rmsnorm(L.ptr(xp), L.ptr(w_d), L.ptr(out), mts, d, 1e-5,
                                  L.BF16 if dt == torch.bfloat16 else L.F32, L.stream()), "rmsnorm")
     ref = O.rms_norm(x.float(), w, 1e-5, dt)
     _close(unpack_act(out, M), ref, dt, "rmsnorm")
@@ -110,7 +112,8 @@ def test_gemm_swiglu(dt, M, F, K, tiles):
     w13 = torch.stack([pack_weight(w1.to(dev)), pack_weight(w3.to(dev))], dim=1).flatten(0, 1).contiguous()
     kc = 32 if dt == torch.bfloat16 else 16
     out = torch.zeros(F // kc, mts, 64, kc // 4, dtype=dt, device=dev)
-    L.check(L.lib().lgen_gemm(L.ptr(w13), L.ptr(pack_act(x.to(dev), mts)), L.ptr(out), M, mts, 2 * F, K, L.EPI_SWIGLU,
+    xp = pack_act(x.to(dev), mts)
+    L.check(L.lib().lgen_gemm(L.ptr(w13), L.ptr(xp), L.ptr(out), M, mts, 2 * F, K, L.EPI_SWIGLU,
                               code, mt, nt, kw, L.stream()), "gemm swiglu")
     a1, a3 = O.linear(x.float(), w1.float(), dt), O.linear(x.float(), w3.float(), dt)
     ref = O._rnd(O._rnd(torch.nn.functional.silu(a1), dt) * a3, dt)
@@ -140,8 +143,9 @@ def test_qkv_rope_append_and_attention(dt, B2, H, hd, grid, pos):
     vc_d[..., :hd] = vcache.to(dev)
     q_d = torch.zeros(mts * 16, H, hdp, dtype=dt, device=dev)
     state = torch.tensor([pos, 0], dtype=torch.int32, device=dev)
-    L.check(L.lib().lgen_gemm_qkv_rope(L.ptr(pack_weight(w.to(dev))), L.ptr(pack_act(x.to(dev), mts)), L.ptr(q_d), L.ptr(kc_d),
-                                       L.ptr(vc_d), L.ptr(freqs.to(dev)), L.ptr(state), B2, mts, d, H, hd, hdp, S8, code,
+    wp, xp, fr_d = pack_weight(w.to(dev)), pack_act(x.to(dev), mts), freqs.to(dev)  # keep alive across the launch
+    L.check(L.lib().lgen_gemm_qkv_rope(L.ptr(wp), L.ptr(xp), L.ptr(q_d), L.ptr(kc_d),
+                                       L.ptr(vc_d), L.ptr(fr_d), L.ptr(state), B2, mts, d, H, hd, hdp, S8, code,
                                        min(mts, 4), 1, 4, L.stream()), "qkv")
     qkv = O.linear(x.float(), w.float(), dt)
     xq, xk, xv = qkv.split([d, d, d], dim=-1)
@@ -193,7 +197,8 @@ def test_sampler_index_exact(dt, B, V, cfg, interval, step, temp, topk, greedy):
     cur = torch.zeros(B2, dtype=torch.int32, device=dev)
     seq = torch.full((B, 16), -1, dtype=torch.int32, device=dev)
     state = torch.tensor([10 + step, step], dtype=torch.int32, device=dev)
-    L.check(L.lib().lgen_sample(L.ptr(logits.to(dev)), L.ptr(noise.to(dev)), L.ptr(cur), L.ptr(seq), L.ptr(state), B, V, 16,
+    lg_d, nz_d = logits.to(dev), noise.to(dev)
+    L.check(L.lib().lgen_sample(L.ptr(lg_d), L.ptr(nz_d), L.ptr(cur), L.ptr(seq), L.ptr(state), B, V, 16,
                                 1 if use_cfg else 0, cfg, interval, temp, topk, 1.0, greedy, 1, code, L.stream()), "sample")
     flag = not (step > 0 and interval > -1 and (step - 1) > interval)
     mixed = O.cfg_mix(logits.float(), cfg, flag)

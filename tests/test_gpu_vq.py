@@ -1,0 +1,152 @@
+"""GPU parity tests of the VQ tokenizer path (decode_code, codebook argmin) against the CPU oracle
+and the reference-made goldens.  Tolerance: decoded pixels within 1e-3 abs (BASELINE.json north_star);
+argmin indices bit-exact."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import llamagen_oracle as O  # noqa: E402
+from tests.cases import VQ_CASES, make_vq_inputs  # noqa: E402
+from tests.util import build_vq_holder, load_golden  # noqa: E402
+
+
+def _dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _L():
+    from llamagen_amd import _lib
+    return _lib
+
+
+def _rand(shape, seed, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def _planes(x, dev):
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    return hi.to(dev).contiguous(), lo.to(dev).contiguous()
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 4, 4, 128), (3, 24, 24, 512), (1, 48, 40, 256)])
+def test_gn_stats_and_split(B, H, W, C):
+    L, dev = _L(), _dev()
+    x = _rand((B, H, W, C), 1) * 2 + 0.5
+    gamma, beta = 1 + 0.1 * _rand((C,), 2), 0.1 * _rand((C,), 3)
+    xd = x.to(dev).contiguous()
+    hw = H * W
+    nchunk = 7
+    ws = torch.empty(B * nchunk * 64, dtype=torch.float64, device=dev)
+    st = torch.empty(B, 32, 2, device=dev)
+    L.check(L.lib().lgen_gn_stats(L.ptr(xd), L.ptr(ws), L.ptr(st), B, hw, C, 1e-6, nchunk, L.stream()), "stats")
+    xg = x.permute(0, 3, 1, 2).reshape(B, 32, -1).double()
+    mean, var = xg.mean(-1), xg.var(-1, unbiased=False)
+    np.testing.assert_allclose(st[..., 0].cpu().numpy(), mean.float().numpy(), atol=2e-6)
+    np.testing.assert_allclose(st[..., 1].cpu().numpy(), (1 / torch.sqrt(var + 1e-6)).float().numpy(), rtol=2e-6)
+    hi = torch.empty(B * hw * C, dtype=torch.bfloat16, device=dev)
+    lo = torch.empty_like(hi)
+    g_d, b_d = gamma.to(dev), beta.to(dev)
+    L.check(L.lib().lgen_gn_swish_split(L.ptr(xd), L.ptr(st), L.ptr(g_d), L.ptr(b_d), L.ptr(hi), L.ptr(lo), B, hw, C, 3,
+                                        L.stream()), "split")
+    ref = O.swish(O.group_norm(x.permute(0, 3, 1, 2), gamma, beta)).permute(0, 2, 3, 1).reshape(-1)
+    got = hi.float().cpu() + lo.float().cpu()
+    assert (got - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,ups,res,nchw", [
+    (2, 4, 4, 256, 512, 3, 0, 0, 0), (1, 24, 24, 512, 512, 3, 0, 1, 0), (2, 6, 10, 128, 128, 3, 1, 0, 0),
+    (1, 3, 5, 512, 256, 1, 0, 0, 0), (2, 16, 16, 128, 3, 3, 0, 0, 1), (1, 9, 7, 64, 64, 3, 0, 1, 0),
+])
+def test_conv_igemm_vs_fp32_conv(B, H, W, Cin, Cout, k, ups, res, nchw):
+    from llamagen_amd.vq_engine import _ConvW
+    L, dev = _L(), _dev()
+
+    class Cv:  # minimal holder
+        pass
+    cv = Cv()
+    cv.weight = (_rand((Cout, Cin, k, k), 4) / (Cin * k * k) ** 0.5).to(dev)
+    cv.bias = (0.1 * _rand((Cout,), 5)).to(dev)
+    cw = _ConvW(cv)
+    Hs, Ws = (H // 2, W // 2) if ups else (H, W)
+    x = _rand((B, Hs, Ws, Cin), 6)
+    r = _rand((B, H, W, Cout), 7) if res else None
+    hi, lo = _planes(x.reshape(-1), dev)
+    r_d = r.to(dev).contiguous() if res else None
+    out = torch.empty(B * H * W * Cout, device=dev)
+    L.check(L.lib().lgen_conv_igemm(L.ptr(hi), L.ptr(lo), L.ptr(cw.hi), L.ptr(cw.lo), L.ptr(cw.bias), L.ptr(r_d), L.ptr(out),
+                                    B, H, W, Cin, Cout, cw.npad, k, ups, nchw, 0, 1.0, L.stream()), "conv")
+    xin = x.permute(0, 3, 1, 2)
+    if ups:
+        xin = xin.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
+    ref = F.conv2d(xin.double(), cv.weight.cpu().double(), cv.bias.cpu().double(), padding=k // 2).float()
+    if res:
+        ref = ref + r.permute(0, 3, 1, 2)
+    got = out.cpu().view(B, Cout, H, W) if nchw else out.cpu().view(B, H, W, Cout).permute(0, 3, 1, 2)
+    err = (got - ref).abs().max().item()
+    assert err < 5e-5 * max(1.0, ref.abs().max().item()), err
+
+
+def test_lookup_pqconv_and_argmin_edges():
+    L, dev = _L(), _dev()
+    case = VQ_CASES["argmin_6x6"]
+    m, sd = build_vq_holder(case)
+    m = m.to(dev)
+    eng = m._eng()
+    cb = sd["quantize.embedding.weight"]
+    np.testing.assert_allclose(eng.cbn.cpu().numpy(), O.l2_normalize(cb).numpy(), atol=1e-7)
+    # exact codebook hits come back as themselves; empty batch works
+    zhit = O.l2_normalize(cb)[[5, 9, 16383, 0]].t().reshape(1, 8, 2, 2)
+    assert m.quantize_indices(zhit.to(dev)).cpu().tolist() == [5, 9, 16383, 0]
+    assert m.quantize_indices(torch.zeros(0, 8, 2, 2, device=dev)).numel() == 0
+
+
+@pytest.mark.parametrize("name", [k for k, c in VQ_CASES.items() if c["kind"] == "argmin"])
+def test_argmin_matches_reference_golden(name):
+    case = VQ_CASES[name]
+    gold = load_golden("vq_" + name)
+    m, sd = build_vq_holder(case)
+    m = m.to(_dev())
+    z = make_vq_inputs(case)["z"]
+    idx = m.quantize_indices(z.to(_dev()))
+    assert idx.dtype == torch.int64
+    np.testing.assert_array_equal(idx.cpu().numpy(), gold["indices"])
+    np.testing.assert_array_equal(idx.cpu().numpy(), O.codebook_argmin(sd["quantize.embedding.weight"], z).numpy())
+
+
+@pytest.mark.parametrize("name", [k for k, c in VQ_CASES.items() if c["kind"] == "decode"])
+def test_decode_code_matches_reference_golden(name):
+    """decode_code pixels within 1e-3 abs of the reference's own output (golden) and of the oracle."""
+    case = VQ_CASES[name]
+    gold = load_golden("vq_" + name)
+    m, sd = build_vq_holder(case)
+    m = m.to(_dev())
+    inp = make_vq_inputs(case)
+    img = m.decode_code(inp["codes"].to(_dev()), inp["shape"])
+    assert img.dtype == torch.float32 and tuple(img.shape) == gold["image"].shape
+    err = np.abs(img.cpu().numpy() - gold["image"]).max()
+    assert err < 1e-3, err
+    ref = O.vq_decode_code(sd, inp["codes"], inp["shape"], ch_mult=tuple(m.config.decoder_ch_mult))
+    assert (img.cpu() - ref).abs().max().item() < 1e-3
+    print(name, "max abs pixel err vs reference golden:", err)
+
+
+def test_decode_quant_path_and_larger_grid():
+    """decode(quant) == decode_code(codes) and a 24x24 latent (384 px) runs and matches the oracle."""
+    case = VQ_CASES["vq16_4x4"]
+    m, sd = build_vq_holder(case)
+    dev = _dev()
+    m = m.to(dev)
+    g = torch.Generator().manual_seed(5)
+    codes = torch.randint(0, 16384, (1, 576), generator=g)
+    img = m.decode_code(codes.to(dev), [1, 8, 24, 24])
+    quant = O.get_codebook_entry(sd["quantize.embedding.weight"], codes, [1, 8, 24, 24])
+    img2 = m.decode(quant.to(dev))
+    assert (img - img2).abs().max().item() < 1e-5
+    ref = O.vq_decode_code(sd, codes, [1, 8, 24, 24])
+    err = (img.cpu() - ref).abs().max().item()
+    assert tuple(img.shape) == (1, 3, 384, 384) and err < 1e-3, err

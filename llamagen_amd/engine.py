@@ -116,6 +116,7 @@ class DecodeEngine:
         self.state = z(2, dtype=torch.int32)                 # [pos, step]
         self.use_mask = False  # True once causal_mask deviates from pure causal (t2i emb_masks)
         self._graphs = {}
+        self._prof = None
         self._pack(model)
 
     # ---- weights --------------------------------------------------------------------------
@@ -196,8 +197,14 @@ class DecodeEngine:
             L.check(lib.lgen_gemm_qkv_rope(L.ptr(w["wqkv"]), L.ptr(self.xnp), L.ptr(self.qbuf), L.ptr(self.k_cache[i]),
                                            L.ptr(self.v_cache[i]), L.ptr(self.freqs_cis), pos_ptr, M, mts, d, H, hd, hdp,
                                            S8, dt, tq[0], tq[1], tq[2], st), "gemm_qkv_rope")
+            if self._prof is not None:  # bench.py roofline leg: HIP events on the launch stream
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             L.check(lib.lgen_attn_decode(L.ptr(self.qbuf), L.ptr(self.k_cache[i]), L.ptr(self.v_cache[i]), L.ptr(self.ap),
                                          pos_ptr, L.ptr(pm), M, mts, H, hd, hdp, S8, dt, st), "attn_decode")
+            if self._prof is not None:
+                e1.record()
+                self._prof["events"].append((e0, e1))
             self.gemm(w["wo"], self.ap, self.hp, M, mts, d, d, L.EPI_RES)
             L.check(lib.lgen_rmsnorm(L.ptr(self.hp), L.ptr(w["fn"]), L.ptr(self.xnp), mts, d, self.eps, dt, st), "rmsnorm")
             self.gemm(w["w13"], self.xnp, self.gp, M, mts, 2 * F, d, L.EPI_SWIGLU)
@@ -246,6 +253,7 @@ class DecodeEngine:
         """prefill + (N-1) decode steps; returns int32 [B, N].  sp: sampling parameter dict."""
         N = max_new_tokens
         T = 1 if model.model_type == "c2i" else cond_combined.shape[1]
+        self._prof = getattr(model, "_prof", None)
         self.state.zero_()
         if emb_masks is not None:  # generate.py:154-163: fold emb_masks into causal_mask, force the diagonal
             cm = self.causal_mask

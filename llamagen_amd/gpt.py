@@ -180,6 +180,7 @@ class Transformer(nn.Module):
         self.causal_mask = None
         self.freqs_cis = None
         self._engine = None
+        self._prof = None
 
     # ---- reference API -------------------------------------------------------------
     def setup_caches(self, max_batch_size: int, max_seq_length: int, dtype: torch.dtype):

@@ -391,10 +391,9 @@ def codebook_argmin(codebook: Tensor, z: Tensor, l2_norm: bool = True) -> Tensor
 def group_norm(x: Tensor, w: Tensor, b: Tensor, groups: int = 32, eps: float = 1e-6) -> Tensor:
     """nn.GroupNorm(32, C, eps=1e-6, affine=True), vq_model.py:359-362 (biased variance)."""
     B, C, H, W = x.shape
-    xg = x.reshape(B, groups, -1).double()
-    mean = xg.mean(-1, keepdim=True)
-    var = xg.var(-1, unbiased=False, keepdim=True)
-    y = ((xg - mean) / torch.sqrt(var + eps)).float().reshape(B, C, H, W)
+    xg = x.reshape(B, groups, -1)
+    var, mean = torch.var_mean(xg, dim=-1, unbiased=False, keepdim=True)
+    y = ((xg - mean) * torch.rsqrt(var + eps)).reshape(B, C, H, W)
     return y * w.view(1, C, 1, 1) + b.view(1, C, 1, 1)
 
 

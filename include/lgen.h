@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define LGEN_ABI_VERSION 1
+#define LGEN_ABI_VERSION 2
 #define LGEN_BF16 0
 #define LGEN_F32 1
 
@@ -33,31 +33,51 @@ extern "C" {
 #define LGEN_EPI_GELU 2   /* out = XP of gelu_tanh(.) (CaptionEmbedder MLP fc1, gpt.py:118-131)      */
 #define LGEN_EPI_RES 3    /* out (XP, in/out) += result: wo / w2 + residual (gpt.py:238-240,255-256) */
 #define LGEN_EPI_SWIGLU 4 /* W = row-tile-interleaved w1||w3, out = XP of silu(w1x)*w3x (gpt.py:167) */
+#define LGEN_EPI_QKV 5    /* lgen_gemm_qkv_rope only (lgen_gemm_max_kw query)                         */
 
 int lgen_abi_version(void);
 
 /* ---- GPT decode step ------------------------------------------------------------------- */
 
 /* nn.Embedding gather (gpt.py:78-83 LabelEmbedder / :351 tok_embeddings) -> packed residual stream.
- * table [rows][d] storage dtype, idx int32 [M] (device), hp = XP[d/KC][MTs]. */
-int lgen_embed_pack(const void* table, const int* idx, void* hp, int M, int MTs, int d, int rows, int dtype,
-                    void* stream);
+ * table [rows][d] storage dtype, idx int32 [M] (device), hp = XP[d/KC][MTs]; ssq_out (nullable):
+ * [d/KC][MTs*16] fp32 partial row sums of squares for the first fused RMSNorm; state_advance (nullable):
+ * device {pos, step}, both incremented before the rest of the decode step reads them (the
+ * `input_pos += 1` of generate.py:118). */
+int lgen_embed_pack(const void* table, const int* idx, void* hp, float* ssq_out, int* state_advance, int M, int MTs,
+                    int d, int rows, int dtype, void* stream);
+
+/* Row sums of squares of an already packed residual stream hp = XP[d/KC][MTs] (t2i prefix rows produced
+ * by the CaptionEmbedder MLP): ssq_out [d/KC][MTs*16] fp32, the ssq_in of a fused RMSNorm. */
+int lgen_ssq_pack(const void* hp, float* ssq_out, int MTs, int d, int dtype, void* stream);
 
 /* RMSNorm.forward (gpt.py:143-148) on XP -> XP, fp32 math, two storage roundings. */
 int lgen_rmsnorm(const void* hp, const void* weight, void* xnp, int MTs, int d, float eps, int dtype, void* stream);
 
 /* Bias-free nn.Linear (gpt.py:161-163,199-200,287) out = x . W^T with fused epilogue, fp32
  * accumulate on MFMA, one storage rounding of the linear output.  (mt, nt, kw) = tile shape:
- * m-tiles per workgroup (divides MTs), n-tiles per workgroup, waves splitting K. */
+ * m-tiles per workgroup (divides MTs), n-tiles per workgroup, waves splitting K.
+ * RMSNorm fusion (gpt.py:137-148, the norm that precedes wqkv / w1,w3 / output in gpt.py:253-256,367):
+ *   norm_w != NULL (ROWS, SWIGLU): x is the un-normalised residual stream and the kernel applies
+ *     rnd(rnd(x * rsqrt(mean(x^2) + eps)) * norm_w) to the operand on the fly; mean(x^2) comes from
+ *     ssq_in[ssq_parts][MTs*16] fp32 partial row sums of squares (summed in a fixed order);
+ *   ssq_out != NULL (RES only): also writes ssq_out[N/16][MTs*16], the per-(16-column tile, row) sums of
+ *     squares of the updated residual stream, i.e. the ssq_in (ssq_parts = N/16) of the next norm. */
 int lgen_gemm(const void* wp, const void* xp, void* out, int M, int MTs, int N, int K, int epilogue_kind, int dtype,
-              int mt, int nt, int kw, void* stream);
+              int mt, int nt, int kw, const void* norm_w, const float* ssq_in, int ssq_parts, float eps,
+              float* ssq_out, void* stream);
 
-/* Attention.forward front half (gpt.py:214-226): wqkv GEMM + apply_rotary_emb(q,k) (gpt.py:420-430)
- * + KVCache.update at *pos_ptr (gpt.py:177-185).  q_out [MTs*16][H][hdp]; caches [B2][H][S8][hdp];
- * freqs [P][hd/2][2] fp32 from precompute_freqs_cis_2d (gpt.py:404-417). */
+/* Largest kw (K-splitting waves per workgroup) the (mt, nt) tile shape of that kernel variant admits. */
+int lgen_gemm_max_kw(int epilogue_kind, int fused_norm, int mt, int nt);
+
+/* Attention.forward front half (gpt.py:214-226): [attention_norm, gpt.py:254 +] wqkv GEMM +
+ * apply_rotary_emb(q,k) (gpt.py:420-430) + KVCache.update at *pos_ptr (gpt.py:177-185).
+ * q_out [MTs*16][H][hdp]; caches [B2][H][S8][hdp]; freqs [P][hd/2][2] fp32 from
+ * precompute_freqs_cis_2d (gpt.py:404-417); norm_w / ssq_in / ssq_parts / eps as in lgen_gemm. */
 int lgen_gemm_qkv_rope(const void* wp, const void* xp, void* q_out, void* k_cache, void* v_cache, const float* freqs,
                        const int* pos_ptr, int M, int MTs, int d, int n_head, int hd, int hdp, int S8, int dtype,
-                       int mt, int nt, int kw, void* stream);
+                       int mt, int nt, int kw, const void* norm_w, const float* ssq_in, int ssq_parts, float eps,
+                       void* stream);
 
 /* Attention.forward back half (gpt.py:229-236): repeat_interleave + math-backend SDPA with
  * causal_mask[:, pos] -- here: single-query attention over the first *pos_ptr+1 cache slots.
@@ -69,11 +89,12 @@ int lgen_attn_decode(const void* q, const void* k_cache, const void* v_cache, vo
 
 /* generate.py:79-86,94-99 (CFG mix) + :57-66 sample() + :16-54 top_k_top_p_filtering +
  * torch.multinomial(1) == argmax(p / noise).  logits [>=2B][V] storage dtype (rows [0,B) cond,
- * [B,2B) uncond when use_cfg); noise [B][V] fp32 Exp(1) draws; state = {pos, step} device ints.
- * Writes cur_tok[b] (and cur_tok[B+b]), seq[b][step]; advance != 0 bumps pos and step. */
-int lgen_sample(const void* logits, const float* noise, int* cur_tok, int* seq, int* state, int B, int V,
-                int seq_stride, int use_cfg, float cfg_scale, int cfg_interval, float temperature, int top_k,
-                float top_p, int greedy, int advance, int dtype, void* stream);
+ * [B,2B) uncond when use_cfg); noise fp32 Exp(1) draws: row b of this call is at
+ * noise[(step * noise_step_stride) + b*V] with step = state[1] (stride 0: one [B][V] block reused);
+ * state = {pos, step} device ints (read only).  Writes cur_tok[b] (and cur_tok[B+b]), seq[b][step]. */
+int lgen_sample(const void* logits, const float* noise, long long noise_step_stride, int* cur_tok, int* seq,
+                const int* state, int B, int V, int seq_stride, int use_cfg, float cfg_scale, int cfg_interval,
+                float temperature, int top_k, float top_p, int greedy, int dtype, void* stream);
 
 int lgen_advance_state(int* state, void* stream);
 

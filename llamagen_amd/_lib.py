@@ -16,7 +16,8 @@ import torch  # noqa: F401  (loads libamdhip64 first)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblgen_hip.so")
 BF16, F32 = 0, 1
-EPI_ROWS, EPI_PACKED, EPI_GELU, EPI_RES, EPI_SWIGLU = 0, 1, 2, 3, 4
+EPI_ROWS, EPI_PACKED, EPI_GELU, EPI_RES, EPI_SWIGLU, EPI_QKV = 0, 1, 2, 3, 4, 5
+ABI_VERSION = 2
 ERR_UNSUPPORTED = -2
 
 _c = ctypes
@@ -25,12 +26,15 @@ _P, _I, _F = _c.c_void_p, _c.c_int, _c.c_float
 # name -> argtypes; the single source of truth for tests/test_abi.py as well
 SIGNATURES = {
     "lgen_abi_version": [],
-    "lgen_embed_pack": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "lgen_embed_pack": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "lgen_ssq_pack": [_P, _P, _I, _I, _I, _P],
     "lgen_rmsnorm": [_P, _P, _P, _I, _I, _F, _I, _P],
-    "lgen_gemm": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
-    "lgen_gemm_qkv_rope": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "lgen_gemm": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _F, _P, _P],
+    "lgen_gemm_max_kw": [_I, _I, _I, _I],
+    "lgen_gemm_qkv_rope": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _F, _P],
+    "lgen_set_attn_variant": [_I],
     "lgen_attn_decode": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
-    "lgen_sample": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _F, _I, _F, _I, _I, _I, _P],
+    "lgen_sample": [_P, _P, _c.c_longlong, _P, _P, _P, _I, _I, _I, _I, _F, _I, _F, _I, _F, _I, _I, _P],
     "lgen_advance_state": [_P, _P],
     "lgen_vq_codebook_prep": [_P, _P, _P, _I, _I, _I, _P],
     "lgen_vq_lookup_pqconv": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],

@@ -1,11 +1,14 @@
 // Skinny weight-streaming GEMM for the decode step: out[M, N] = x[M, K] . W[N, K]^T with
-// M = CFG-doubled batch (1..256), i.e. HBM-bound on the weight stream.
+// M = CFG-doubled batch (1..256), i.e. HBM/latency-bound on the weight stream.
 //
 // Replaces the nn.Linear calls of the reference decode step
 // (autoregressive/models/gpt.py:161-163 w1/w3/w2, :199-200 wqkv/wo, :287 output) and fuses
 // what the reference does around them:
+//   NORM prologue : RMSNorm of the input rows (gpt.py:143-148) applied to the B operand on the fly;
+//                   the row sums of squares arrive as partials written by the producer kernel
 //   EPI_QKV    : wqkv + apply_rotary_emb(q, k) + KVCache.update   (gpt.py:214-226, 177-185, 420-430)
-//   EPI_RES    : wo / w2 + residual add                           (gpt.py:238-240, 255-256)
+//   EPI_RES    : wo / w2 + residual add (gpt.py:238-240, 255-256) [+ partial row sums of squares of
+//                the new residual stream for the next RMSNorm]
 //   EPI_SWIGLU : silu(w1 x) * w3 x on a row-interleaved w1||w3    (gpt.py:167)
 //   EPI_ROWS   : row-major output (lm_head logits, gpt.py:367-368)
 //   EPI_PACKED / EPI_GELU : plain / gelu(tanh) packed output (CaptionEmbedder MLP, gpt.py:118-131)
@@ -14,8 +17,10 @@
 // every wave-level load is one fully coalesced 1 KiB `global_load_dwordx4`, straight into the
 // VGPRs that feed `v_mfma_f32_16x16x32_bf16` (or 4 x `v_mfma_f32_16x16x4_f32` in fp32 mode):
 // no LDS staging, no barriers in the main loop.  A workgroup owns NT 16-row tiles of N for all
-// M rows; its KW waves split K between them and combine through LDS in a fixed order
-// (deterministic, no atomics).  Weights are loaded non-temporally (read once per step).
+// M rows; its KW waves split K between them, each keeps DEPTH k-chunks of loads in flight
+// (register ring, static indices) and they combine through LDS in a fixed order (deterministic,
+// no atomics).  Weights are loaded non-temporally (read once per step).  Everything an epilogue
+// needs from memory (residual tile, RoPE angles) is requested before the main loop.
 #include "lgen_common.h"
 #include "../../include/lgen.h"
 
@@ -29,8 +34,13 @@ struct GemmArgs {
     void* vc;            // QKV: v cache
     const float* freqs;  // QKV: [P][hd/2][2] fp32 (cos, sin)
     const int* pos_ptr;  // QKV: device scalar, position of this token
+    const uint4* nw;     // NORM: RMSNorm weight [K] storage dtype
+    const float* ssq_in; // NORM: [parts][MTs*16] partial sums of squares of the x rows
+    float* ssq_out;      // RES: [N/16][MTs*16] partial sums of squares of the new rows (nullable)
     int N, KCH, MTs, M;
     int d, hd, hdp, H, S8;
+    int parts;
+    float eps, inv_k;
 };
 
 LGEN_DEV float silu_f(float x) { return x / (1.0f + expf(-x)); }
@@ -40,9 +50,34 @@ LGEN_DEV float gelu_tanh_f(float x) {
     return 0.5f * x * (1.0f + tanhf(inner));
 }
 
+// memory operands of an epilogue, requested early: RES -> the residual tile, QKV -> RoPE (cos, sin) x 2
+template <typename D, int EPI>
+LGEN_DEV uint4 epi_prefetch(const GemmArgs& a, int nt, int mt, int lane, int pos) {
+    uint4 aux = make_uint4(0, 0, 0, 0);
+    const int r = lane & 15, g = lane >> 4;
+    const int n = nt * 16 + g * 4;
+    if constexpr (EPI == EPI_RES) {
+        const size_t o = D::xp_off(n, mt, r, a.MTs);
+        if constexpr (D::ESZ == 2) {
+            const uint2 v = *(const uint2*)((const uint16_t*)a.out + o);
+            aux.x = v.x; aux.y = v.y;
+        } else {
+            aux = *(const uint4*)((const float*)a.out + o);
+        }
+    } else if constexpr (EPI == EPI_QKV) {
+        const int sec = n / a.d;
+        if (sec < 2) {
+            const int c = n - sec * a.d;
+            const int dd = c % a.hd;
+            aux = *(const uint4*)(a.freqs + ((size_t)pos * (a.hd >> 1) + (dd >> 1)) * 2);
+        }
+    }
+    return aux;
+}
+
 // one 16x16 output tile: lane (g = lane>>4, r = lane&15) holds n = nt*16 + g*4 + {0..3}, m = mt*16 + r
 template <typename D, int EPI>
-LGEN_DEV void epilogue(const GemmArgs& a, int nt, int mt, int lane, f32x4_t v, f32x4_t v2) {
+LGEN_DEV void epilogue(const GemmArgs& a, int nt, int mt, int lane, f32x4_t v, f32x4_t v2, const uint4& aux, int pos) {
     const int r = lane & 15, g = lane >> 4;
     const int m = mt * 16 + r;
     const int n = nt * 16 + g * 4;
@@ -54,10 +89,22 @@ LGEN_DEV void epilogue(const GemmArgs& a, int nt, int mt, int lane, f32x4_t v, f
     } else if constexpr (EPI == EPI_GELU) {
         D::st4(a.out, D::xp_off(n, mt, r, a.MTs), gelu_tanh_f(x0), gelu_tanh_f(x1), gelu_tanh_f(x2), gelu_tanh_f(x3));
     } else if constexpr (EPI == EPI_RES) {
-        size_t o = D::xp_off(n, mt, r, a.MTs);
         float h0, h1, h2, h3;
-        D::ld4(a.out, o, h0, h1, h2, h3);
-        D::st4(a.out, o, h0 + x0, h1 + x1, h2 + x2, h3 + x3);
+        if constexpr (D::ESZ == 2) {
+            h0 = __uint_as_float(aux.x << 16); h1 = __uint_as_float(aux.x & 0xffff0000u);
+            h2 = __uint_as_float(aux.y << 16); h3 = __uint_as_float(aux.y & 0xffff0000u);
+        } else {
+            h0 = __uint_as_float(aux.x); h1 = __uint_as_float(aux.y);
+            h2 = __uint_as_float(aux.z); h3 = __uint_as_float(aux.w);
+        }
+        h0 = D::rnd(h0 + x0); h1 = D::rnd(h1 + x1); h2 = D::rnd(h2 + x2); h3 = D::rnd(h3 + x3);
+        D::st4(a.out, D::xp_off(n, mt, r, a.MTs), h0, h1, h2, h3);
+        if (a.ssq_out) {  // fixed-order partial of sum(h^2) over this tile's 16 columns, per row
+            float ss = ((h0 * h0 + h1 * h1) + h2 * h2) + h3 * h3;
+            ss += __shfl_xor(ss, 16, 64);
+            ss += __shfl_xor(ss, 32, 64);
+            if (lane < 16) a.ssq_out[(size_t)nt * (a.MTs * 16) + m] = ss;
+        }
     } else if constexpr (EPI == EPI_SWIGLU) {
         // nt is the w1 tile (even), v2 the matching w3 tile; output feature f = (nt/2)*16 + g*4
         float y0 = D::rnd(v2[0]), y1 = D::rnd(v2[1]), y2 = D::rnd(v2[2]), y3 = D::rnd(v2[3]);
@@ -66,15 +113,15 @@ LGEN_DEV void epilogue(const GemmArgs& a, int nt, int mt, int lane, f32x4_t v, f
                D::rnd(silu_f(x0)) * y0, D::rnd(silu_f(x1)) * y1, D::rnd(silu_f(x2)) * y2, D::rnd(silu_f(x3)) * y3);
     } else if constexpr (EPI == EPI_QKV) {
         if (m >= a.M) return;
-        const int pos = *a.pos_ptr;
         const int sec = n / a.d;
         const int c = n - sec * a.d;
         const int head = c / a.hd;
         const int dd = c - head * a.hd;
         if (sec < 2) {  // 2-D RoPE on interleaved (even, odd) pairs, fp32, one rounding
-            const float4 f = *(const float4*)(a.freqs + ((size_t)pos * (a.hd >> 1) + (dd >> 1)) * 2);
-            float y0 = x0 * f.x - x1 * f.y, y1 = x1 * f.x + x0 * f.y;
-            float y2 = x2 * f.z - x3 * f.w, y3 = x3 * f.z + x2 * f.w;
+            const float fx = __uint_as_float(aux.x), fy = __uint_as_float(aux.y);
+            const float fz = __uint_as_float(aux.z), fw = __uint_as_float(aux.w);
+            float y0 = x0 * fx - x1 * fy, y1 = x1 * fx + x0 * fy;
+            float y2 = x2 * fz - x3 * fw, y3 = x3 * fz + x2 * fw;
             x0 = y0; x1 = y1; x2 = y2; x3 = y3;
         }
         if (sec == 0) {
@@ -86,19 +133,89 @@ LGEN_DEV void epilogue(const GemmArgs& a, int nt, int mt, int lane, f32x4_t v, f
     }
 }
 
-// VGPR budget: accumulators + two register stages of operands; big tiles run <= 8 waves.
-template <int MT, int NT>
-constexpr int gemm_max_threads() { return (NT * MT * 4 + 2 * (NT + MT) * 4 + 24 > 112) ? 512 : 1024; }
+template <int EPI> constexpr bool epi_has_aux() { return EPI == EPI_RES || EPI == EPI_QKV; }
 
-template <typename D, int MT, int NT, int EPI>
-__global__ __launch_bounds__((gemm_max_threads<MT, NT>())) void gemm_kernel(GemmArgs a) {
+// VGPR budget: DEPTH register stages of operands + accumulators + prefetched epilogue operands
+// (+ RMSNorm scales / weights / temporaries).  DEPTH shrinks for the big tile shapes so that nothing
+// spills; <= 120 registers -> 16 waves (1024 threads) may share a CU's SIMDs, else 8 waves.
+template <int MT, int NT, bool NORM, int EPI>
+constexpr int gemm_fixed_regs() {
+    return NT * MT * 4 + (epi_has_aux<EPI>() ? NT * MT * 4 : 0) + (NORM ? 44 : 0) + (EPI == EPI_QKV ? 16 : 0) + 36;
+}
+template <int MT, int NT, bool NORM, int EPI>
+constexpr int gemm_depth() {
+    constexpr int per_stage = (NT + MT + (NORM ? 1 : 0)) * 4;
+    constexpr int d = (200 - gemm_fixed_regs<MT, NT, NORM, EPI>()) / per_stage;
+    return d < 2 ? 2 : (d > 6 ? 6 : d);
+}
+template <int MT, int NT, bool NORM, int EPI>
+constexpr int gemm_max_threads() {
+    return (gemm_depth<MT, NT, NORM, EPI>() * (NT + MT + (NORM ? 1 : 0)) * 4 + gemm_fixed_regs<MT, NT, NORM, EPI>() > 124) ? 512 : 1024;
+}
+
+template <typename D, int MT, int NT, int EPI, bool NORM, int DEPTH>
+__global__ __launch_bounds__((gemm_max_threads<MT, NT, NORM, EPI>())) void gemm_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) float4 red[];
+    constexpr int TILES = NT * MT;
+    constexpr int UNITS = EPI == EPI_SWIGLU ? (TILES / 2 > 0 ? TILES / 2 : 1) : TILES;   // epilogue work items
+    constexpr int UPW = (UNITS + 1) / 2;                           // max units per wave when KW >= 2
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int KW = blockDim.x >> 6;
     const int nt0 = blockIdx.x * NT;
     const int mt0 = blockIdx.y * MT;
     const int k0 = (int)(((long)a.KCH * w) / KW), k1 = (int)(((long)a.KCH * (w + 1)) / KW);
+    int pos = 0;
+    if constexpr (EPI == EPI_QKV) pos = *a.pos_ptr;
+
+    const uint4* wbase = a.wp + ((size_t)nt0 * a.KCH) * 64 + lane;
+    const uint4* xbase = a.xp + (size_t)mt0 * 64 + lane;
+    const size_t wstride = (size_t)a.KCH * 64;
+    const size_t xstride = (size_t)a.MTs * 64;
+
+    uint4 A[DEPTH][NT], B[DEPTH][MT], WN[DEPTH];
+#define LGEN_LOAD(s, kk)                                                                                  \
+    {                                                                                                     \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j) A[s][j] = ldg_nt(wbase + j * wstride + (size_t)(kk) * 64); \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i) B[s][i] = xbase[(size_t)(kk) * xstride + i * 64];  \
+        if constexpr (NORM) WN[s] = a.nw[(size_t)(kk) * 4 + (lane >> 4)];                                \
+    }
+    // 1. fill the ring
+#pragma unroll
+    for (int s = 0; s < DEPTH; ++s)
+        if (k0 + s < k1) LGEN_LOAD(s, k0 + s);
+
+    // 2. request what the epilogue will need (this wave's units: u = w, w + KW, ...; KW == 1: all)
+    //    (q >= UPW never matches when KW >= 2, so aux[q] lines up with the epilogue loops below)
+    uint4 aux[UNITS];
+#pragma unroll
+    for (int q = 0; q < UNITS; ++q) aux[q] = make_uint4(0, 0, 0, 0);
+    if constexpr (epi_has_aux<EPI>()) {
+#pragma unroll
+        for (int q = 0; q < UNITS; ++q) {
+            const int u = w + q * KW;
+            if (u < UNITS) {
+                const int j = u / MT, i = u - j * MT;
+                aux[q] = epi_prefetch<D, EPI>(a, nt0 + j, mt0 + i, lane, pos);
+            }
+        }
+    }
+
+    // 3. RMSNorm row scales from the producer's partial sums of squares (fixed order)
+    float ri[MT];
+    if constexpr (NORM) {
+        const int R = a.MTs * 16;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const float* p = a.ssq_in + (size_t)(mt0 + i) * 16 + (lane & 15);
+            float s = 0.f;
+#pragma unroll 4
+            for (int q = lane >> 4; q < a.parts; q += 4) s += p[(size_t)q * R];
+            s += __shfl_xor(s, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            ri[i] = 1.0f / sqrtf(s * a.inv_k + a.eps);
+        }
+    }
 
     f32x4_t acc[NT][MT];
 #pragma unroll
@@ -106,49 +223,48 @@ __global__ __launch_bounds__((gemm_max_threads<MT, NT>())) void gemm_kernel(Gemm
 #pragma unroll
         for (int i = 0; i < MT; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    const uint4* wbase = a.wp + ((size_t)nt0 * a.KCH) * 64 + lane;
-    const uint4* xbase = a.xp + (size_t)mt0 * 64 + lane;
-    const size_t wstride = (size_t)a.KCH * 64;
-    const size_t xstride = (size_t)a.MTs * 64;
-
-    uint4 A0[NT], B0[MT], A1[NT], B1[MT];
-#define LGEN_LOAD(A, B, kk)                                                                   \
-    {                                                                                         \
-        _Pragma("unroll") for (int j = 0; j < NT; ++j) A[j] = ldg_nt(wbase + j * wstride + (size_t)(kk) * 64); \
-        _Pragma("unroll") for (int i = 0; i < MT; ++i) B[i] = xbase[(size_t)(kk) * xstride + i * 64];          \
+#define LGEN_MMA(s)                                                                                       \
+    {                                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                                  \
+            uint4 b_ = B[s][i];                                                                           \
+            if constexpr (NORM) b_ = D::norm_chunk(b_, ri[i], WN[s]);                                     \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j) acc[j][i] = D::mma(A[s][j], b_, acc[j][i]);    \
+        }                                                                                                 \
     }
-#define LGEN_MMA(A, B)                                                                        \
-    {                                                                                         \
-        _Pragma("unroll") for (int j = 0; j < NT; ++j)                                        \
-            _Pragma("unroll") for (int i = 0; i < MT; ++i) acc[j][i] = D::mma(A[j], B[i], acc[j][i]); \
-    }
+    // 4. main loop: consume stage s, refill it DEPTH chunks ahead
     int k = k0;
-    if (k < k1) {
-        LGEN_LOAD(A0, B0, k);
-        while (true) {
-            if (k + 1 < k1) LGEN_LOAD(A1, B1, k + 1);
-            LGEN_MMA(A0, B0);
-            if (++k >= k1) break;
-            if (k + 1 < k1) LGEN_LOAD(A0, B0, k + 1);
-            LGEN_MMA(A1, B1);
-            if (++k >= k1) break;
+    while (k + 2 * DEPTH <= k1) {
+#pragma unroll
+        for (int s = 0; s < DEPTH; ++s) {
+            LGEN_MMA(s);
+            LGEN_LOAD(s, k + s + DEPTH);
+        }
+        k += DEPTH;
+    }
+#pragma unroll
+    for (int s = 0; s < DEPTH; ++s) {
+        if (k + s < k1) {
+            LGEN_MMA(s);
+            if (k + s + DEPTH < k1) LGEN_LOAD(s, k + s + DEPTH);
         }
     }
+    k += DEPTH;
+#pragma unroll
+    for (int s = 0; s < DEPTH; ++s)
+        if (k + s < k1) LGEN_MMA(s);
 #undef LGEN_LOAD
 #undef LGEN_MMA
 
-    constexpr int TILES = NT * MT;
     if (KW == 1) {
-        if constexpr (EPI == EPI_SWIGLU) {
 #pragma unroll
-            for (int j = 0; j < NT; j += 2)
-#pragma unroll
-                for (int i = 0; i < MT; ++i) epilogue<D, EPI>(a, nt0 + j, mt0 + i, lane, acc[j][i], acc[(j + 1) % NT][i]);
-        } else {
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-#pragma unroll
-                for (int i = 0; i < MT; ++i) epilogue<D, EPI>(a, nt0 + j, mt0 + i, lane, acc[j][i], acc[j][i]);
+        for (int q = 0; q < UNITS; ++q) {
+            if constexpr (EPI == EPI_SWIGLU) {
+                const int jp = q / MT, i = q - jp * MT;
+                epilogue<D, EPI>(a, nt0 + 2 * jp, mt0 + i, lane, acc[2 * jp][i], acc[(2 * jp + 1) % NT][i], aux[q], pos);
+            } else {
+                const int j = q / MT, i = q - j * MT;
+                epilogue<D, EPI>(a, nt0 + j, mt0 + i, lane, acc[j][i], acc[j][i], aux[q], pos);
+            }
         }
         return;
     }
@@ -169,41 +285,55 @@ __global__ __launch_bounds__((gemm_max_threads<MT, NT>())) void gemm_kernel(Gemm
         }
         return f32x4_t{s.x, s.y, s.z, s.w};
     };
-    if constexpr (EPI == EPI_SWIGLU) {
-        constexpr int UNITS = (NT / 2) * MT;
-        for (int u = w; u < UNITS; u += KW) {
-            int jp = u / MT, i = u - jp * MT;
-            epilogue<D, EPI>(a, nt0 + 2 * jp, mt0 + i, lane, rsum((2 * jp) * MT + i), rsum((2 * jp + 1) * MT + i));
-        }
-    } else {
-        for (int t = w; t < TILES; t += KW) {
-            int j = t / MT, i = t - j * MT;
-            f32x4_t v = rsum(t);
-            epilogue<D, EPI>(a, nt0 + j, mt0 + i, lane, v, v);
+#pragma unroll
+    for (int q = 0; q < UPW; ++q) {
+        const int u = w + q * KW;
+        if (u < UNITS) {
+            if constexpr (EPI == EPI_SWIGLU) {
+                const int jp = u / MT, i = u - jp * MT;
+                epilogue<D, EPI>(a, nt0 + 2 * jp, mt0 + i, lane, rsum((2 * jp) * MT + i), rsum((2 * jp + 1) * MT + i), aux[q], pos);
+            } else {
+                const int j = u / MT, i = u - j * MT;
+                const f32x4_t v = rsum(u);
+                epilogue<D, EPI>(a, nt0 + j, mt0 + i, lane, v, v, aux[q], pos);
+            }
         }
     }
 }
 
-template <typename D, int MT, int NT, int EPI>
+template <typename D, int MT, int NT, int EPI, bool NORM>
 static int launch(const GemmArgs& a, int kw, hipStream_t st) {
+    constexpr int DEPTH = gemm_depth<MT, NT, NORM, EPI>();
     dim3 grid((a.N / 16) / NT, a.MTs / MT);
     size_t lds = kw > 1 ? (size_t)kw * NT * MT * 64 * sizeof(float4) : 0;
-    if (lds > 160 * 1024 || kw * 64 > gemm_max_threads<MT, NT>()) return LGEN_ERR_BAD_ARG;
+    if (lds > 160 * 1024 || kw * 64 > gemm_max_threads<MT, NT, NORM, EPI>()) return LGEN_ERR_BAD_ARG;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<D, MT, NT, EPI>,
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<D, MT, NT, EPI, NORM, DEPTH>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL((gemm_kernel<D, MT, NT, EPI>), grid, dim3(64 * kw), lds, st, a);
+    hipLaunchKernelGGL((gemm_kernel<D, MT, NT, EPI, NORM, DEPTH>), grid, dim3(64 * kw), lds, st, a);
     LGEN_CHECK_LAUNCH();
     return 0;
 }
 
-template <typename D, int EPI>
+// the largest K-splitting wave count a (mt, nt) tile shape admits (register budget), for the host heuristics
+template <int EPI, bool NORM>
+static int max_kw_of(int mt, int nt) {
+#define LGEN_CASE(MT_, NT_) if (mt == MT_ && nt == NT_) return gemm_max_threads<MT_, NT_, NORM, EPI>() / 64;
+    LGEN_CASE(1, 1) LGEN_CASE(1, 2) LGEN_CASE(1, 4)
+    LGEN_CASE(2, 1) LGEN_CASE(2, 2) LGEN_CASE(2, 4)
+    LGEN_CASE(4, 1) LGEN_CASE(4, 2) LGEN_CASE(4, 4)
+    LGEN_CASE(8, 1) LGEN_CASE(8, 2)
+#undef LGEN_CASE
+    return 0;
+}
+
+template <typename D, int EPI, bool NORM>
 static int dispatch(const GemmArgs& a, int mt, int nt, int kw, hipStream_t st) {
     if ((a.N / 16) % nt != 0 || a.MTs % mt != 0 || kw < 1 || kw > 16) return LGEN_ERR_BAD_ARG;
     if (EPI == EPI_SWIGLU && (nt & 1)) return LGEN_ERR_BAD_ARG;
-#define LGEN_CASE(MT_, NT_) if (mt == MT_ && nt == NT_) return launch<D, MT_, NT_, EPI>(a, kw, st);
+#define LGEN_CASE(MT_, NT_) if (mt == MT_ && nt == NT_) return launch<D, MT_, NT_, EPI, NORM>(a, kw, st);
     LGEN_CASE(1, 1) LGEN_CASE(1, 2) LGEN_CASE(1, 4)
     LGEN_CASE(2, 1) LGEN_CASE(2, 2) LGEN_CASE(2, 4)
     LGEN_CASE(4, 1) LGEN_CASE(4, 2) LGEN_CASE(4, 4)
@@ -212,34 +342,65 @@ static int dispatch(const GemmArgs& a, int mt, int nt, int kw, hipStream_t st) {
     return LGEN_ERR_BAD_ARG;
 }
 
-template <int EPI>
+template <int EPI, bool NORM>
 static int dispatch_dt(const GemmArgs& a, int dtype, int mt, int nt, int kw, hipStream_t st) {
-    if (dtype == LGEN_BF16) return dispatch<BF16, EPI>(a, mt, nt, kw, st);
-    if (dtype == LGEN_F32) return dispatch<F32, EPI>(a, mt, nt, kw, st);
+    if (dtype == LGEN_BF16) return dispatch<BF16, EPI, NORM>(a, mt, nt, kw, st);
+    if (dtype == LGEN_F32) return dispatch<F32, EPI, NORM>(a, mt, nt, kw, st);
     return LGEN_ERR_BAD_ARG;
 }
 
+// RMSNorm-prologue variants exist for the three consumers of a normalised residual stream
+template <int EPI>
+static int dispatch_norm(const GemmArgs& a, int dtype, int mt, int nt, int kw, hipStream_t st) {
+    if (a.nw) {
+        if constexpr (EPI == EPI_QKV || EPI == EPI_SWIGLU || EPI == EPI_ROWS) {
+            if (!a.ssq_in || a.parts < 1) return LGEN_ERR_BAD_ARG;
+            return dispatch_dt<EPI, true>(a, dtype, mt, nt, kw, st);
+        } else {
+            return LGEN_ERR_UNSUPPORTED;
+        }
+    }
+    return dispatch_dt<EPI, false>(a, dtype, mt, nt, kw, st);
+}
+
+extern "C" int lgen_gemm_max_kw(int epilogue_kind, int fused_norm, int mt, int nt) {
+    switch (epilogue_kind) {
+        case LGEN_EPI_ROWS: return fused_norm ? max_kw_of<EPI_ROWS, true>(mt, nt) : max_kw_of<EPI_ROWS, false>(mt, nt);
+        case LGEN_EPI_PACKED: return max_kw_of<EPI_PACKED, false>(mt, nt);
+        case LGEN_EPI_GELU: return max_kw_of<EPI_GELU, false>(mt, nt);
+        case LGEN_EPI_RES: return max_kw_of<EPI_RES, false>(mt, nt);
+        case LGEN_EPI_SWIGLU: return fused_norm ? max_kw_of<EPI_SWIGLU, true>(mt, nt) : max_kw_of<EPI_SWIGLU, false>(mt, nt);
+        case LGEN_EPI_QKV: return fused_norm ? max_kw_of<EPI_QKV, true>(mt, nt) : max_kw_of<EPI_QKV, false>(mt, nt);
+        default: return 0;
+    }
+}
+
 extern "C" int lgen_gemm(const void* wp, const void* xp, void* out, int M, int MTs, int N, int K, int epilogue_kind,
-                         int dtype, int mt, int nt, int kw, void* stream) {
+                         int dtype, int mt, int nt, int kw, const void* norm_w, const float* ssq_in, int ssq_parts,
+                         float eps, float* ssq_out, void* stream) {
     const int kcsz = dtype == LGEN_BF16 ? 32 : 16;
     if (N % 16 || K % kcsz || M > MTs * 16) return LGEN_ERR_BAD_ARG;
     GemmArgs a{};
     a.wp = (const uint4*)wp; a.xp = (const uint4*)xp; a.out = out;
     a.N = N; a.KCH = K / kcsz; a.MTs = MTs; a.M = M;
+    a.nw = (const uint4*)norm_w; a.ssq_in = ssq_in; a.parts = ssq_parts; a.eps = eps; a.inv_k = 1.0f / (float)K;
+    a.ssq_out = ssq_out;
     hipStream_t st = (hipStream_t)stream;
+    if (ssq_out && epilogue_kind != LGEN_EPI_RES) return LGEN_ERR_BAD_ARG;
     switch (epilogue_kind) {
-        case LGEN_EPI_ROWS: return dispatch_dt<EPI_ROWS>(a, dtype, mt, nt, kw, st);
-        case LGEN_EPI_PACKED: return dispatch_dt<EPI_PACKED>(a, dtype, mt, nt, kw, st);
-        case LGEN_EPI_GELU: return dispatch_dt<EPI_GELU>(a, dtype, mt, nt, kw, st);
-        case LGEN_EPI_RES: return dispatch_dt<EPI_RES>(a, dtype, mt, nt, kw, st);
-        case LGEN_EPI_SWIGLU: return dispatch_dt<EPI_SWIGLU>(a, dtype, mt, nt, kw, st);
+        case LGEN_EPI_ROWS: return dispatch_norm<EPI_ROWS>(a, dtype, mt, nt, kw, st);
+        case LGEN_EPI_PACKED: return dispatch_norm<EPI_PACKED>(a, dtype, mt, nt, kw, st);
+        case LGEN_EPI_GELU: return dispatch_norm<EPI_GELU>(a, dtype, mt, nt, kw, st);
+        case LGEN_EPI_RES: return dispatch_norm<EPI_RES>(a, dtype, mt, nt, kw, st);
+        case LGEN_EPI_SWIGLU: return dispatch_norm<EPI_SWIGLU>(a, dtype, mt, nt, kw, st);
         default: return LGEN_ERR_BAD_ARG;
     }
 }
 
 extern "C" int lgen_gemm_qkv_rope(const void* wp, const void* xp, void* q_out, void* k_cache, void* v_cache,
                                   const float* freqs, const int* pos_ptr, int M, int MTs, int d, int n_head, int hd,
-                                  int hdp, int S8, int dtype, int mt, int nt, int kw, void* stream) {
+                                  int hdp, int S8, int dtype, int mt, int nt, int kw, const void* norm_w,
+                                  const float* ssq_in, int ssq_parts, float eps, void* stream) {
     const int kcsz = dtype == LGEN_BF16 ? 32 : 16;
     if (d % kcsz || (3 * d) % 16 || hd % 4 || d != n_head * hd || M > MTs * 16) return LGEN_ERR_BAD_ARG;
     GemmArgs a{};
@@ -247,5 +408,6 @@ extern "C" int lgen_gemm_qkv_rope(const void* wp, const void* xp, void* q_out, v
     a.freqs = freqs; a.pos_ptr = pos_ptr;
     a.N = 3 * d; a.KCH = d / kcsz; a.MTs = MTs; a.M = M;
     a.d = d; a.hd = hd; a.hdp = hdp; a.H = n_head; a.S8 = S8;
-    return dispatch_dt<EPI_QKV>(a, dtype, mt, nt, kw, (hipStream_t)stream);
+    a.nw = (const uint4*)norm_w; a.ssq_in = ssq_in; a.parts = ssq_parts; a.eps = eps; a.inv_k = 1.0f / (float)d;
+    return dispatch_norm<EPI_QKV>(a, dtype, mt, nt, kw, (hipStream_t)stream);
 }

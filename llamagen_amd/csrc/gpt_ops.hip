@@ -8,13 +8,22 @@
 #include "../../include/lgen.h"
 
 // ---------------------------------------------------------------------------------------------
-// embedding gather: hp[k-chunk][mt][lane] <- table[idx[m]][k..]   (16 B per thread)
+// embedding gather: hp[k-chunk][mt][lane] <- table[idx[m]][k..]   (16 B per thread), plus
+//   * ssq_out[kc][MTs*16]: per-(k-chunk, row) sums of squares = the partials the first fused
+//     RMSNorm (gemm_skinny.hip NORM prologue) sums in a fixed order
+//   * state advance: (pos, step) += 1 before anything of this decode step reads them (the sampler
+//     of the previous step is complete at this kernel's launch boundary)
 // ---------------------------------------------------------------------------------------------
 template <typename D>
 __global__ __launch_bounds__(256) void embed_pack_kernel(const uint4* __restrict__ table, const int* __restrict__ idx,
-                                                         uint4* __restrict__ hp, int M, int MTs, int d, int rows) {
+                                                         uint4* __restrict__ hp, float* __restrict__ ssq_out,
+                                                         int* __restrict__ state, int M, int MTs, int d, int rows) {
     const int KCH = d / D::KC;
-    const int total = KCH * MTs * 64;
+    const int total = KCH * MTs * 64;  // a multiple of 64: every wave is one (kc, mt) chunk
+    if (state && blockIdx.x == 0 && threadIdx.x == 0) {
+        state[0] += 1;
+        state[1] += 1;
+    }
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
         const int lane = t & 63;
         const int mt = (t >> 6) % MTs;
@@ -27,21 +36,67 @@ __global__ __launch_bounds__(256) void embed_pack_kernel(const uint4* __restrict
             v = table[((size_t)row * d + kc * D::KC + (lane >> 4) * D::EPL) / D::EPL];
         }
         hp[t] = v;
+        if (ssq_out) {
+            float f[D::EPL];
+            D::unpack(v, f);
+            float ss = 0.f;
+#pragma unroll
+            for (int e = 0; e < D::EPL; ++e) ss += f[e] * f[e];
+            ss += __shfl_xor(ss, 16, 64);
+            ss += __shfl_xor(ss, 32, 64);
+            if (lane < 16) ssq_out[(size_t)kc * (MTs * 16) + m] = ss;
+        }
     }
 }
 
-extern "C" int lgen_embed_pack(const void* table, const int* idx, void* hp, int M, int MTs, int d, int rows,
-                               int dtype, void* stream) {
+extern "C" int lgen_embed_pack(const void* table, const int* idx, void* hp, float* ssq_out, int* state_advance, int M,
+                               int MTs, int d, int rows, int dtype, void* stream) {
     if (M > MTs * 16 || d % 32) return LGEN_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == LGEN_BF16) {
         int total = (d / 32) * MTs * 64;
         hipLaunchKernelGGL(embed_pack_kernel<BF16>, dim3((total + 255) / 256), dim3(256), 0, st, (const uint4*)table, idx,
-                           (uint4*)hp, M, MTs, d, rows);
+                           (uint4*)hp, ssq_out, state_advance, M, MTs, d, rows);
     } else if (dtype == LGEN_F32) {
         int total = (d / 16) * MTs * 64;
         hipLaunchKernelGGL(embed_pack_kernel<F32>, dim3((total + 255) / 256), dim3(256), 0, st, (const uint4*)table, idx,
-                           (uint4*)hp, M, MTs, d, rows);
+                           (uint4*)hp, ssq_out, state_advance, M, MTs, d, rows);
+    } else {
+        return LGEN_ERR_BAD_ARG;
+    }
+    LGEN_CHECK_LAUNCH();
+    return 0;
+}
+
+// Row sums of squares of an already packed residual stream (t2i prefix rows enter the decode loop
+// from the CaptionEmbedder MLP, not from an embedding gather): ssq_out[kc][MTs*16].
+template <typename D>
+__global__ __launch_bounds__(256) void ssq_pack_kernel(const uint4* __restrict__ hp, float* __restrict__ ssq_out, int total,
+                                                       int MTs) {
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+        const int lane = t & 63;
+        const int mt = (t >> 6) % MTs;
+        const int kc = (t >> 6) / MTs;
+        float f[D::EPL];
+        D::unpack(hp[t], f);
+        float ss = 0.f;
+#pragma unroll
+        for (int e = 0; e < D::EPL; ++e) ss += f[e] * f[e];
+        ss += __shfl_xor(ss, 16, 64);
+        ss += __shfl_xor(ss, 32, 64);
+        if (lane < 16) ssq_out[(size_t)kc * (MTs * 16) + mt * 16 + lane] = ss;
+    }
+}
+
+extern "C" int lgen_ssq_pack(const void* hp, float* ssq_out, int MTs, int d, int dtype, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (d % 32 || !ssq_out) return LGEN_ERR_BAD_ARG;
+    if (dtype == LGEN_BF16) {
+        int total = (d / 32) * MTs * 64;
+        hipLaunchKernelGGL(ssq_pack_kernel<BF16>, dim3((total + 255) / 256), dim3(256), 0, st, (const uint4*)hp, ssq_out, total, MTs);
+    } else if (dtype == LGEN_F32) {
+        int total = (d / 16) * MTs * 64;
+        hipLaunchKernelGGL(ssq_pack_kernel<F32>, dim3((total + 255) / 256), dim3(256), 0, st, (const uint4*)hp, ssq_out, total, MTs);
     } else {
         return LGEN_ERR_BAD_ARG;
     }
@@ -50,31 +105,38 @@ extern "C" int lgen_embed_pack(const void* table, const int* idx, void* hp, int 
 }
 
 // ---------------------------------------------------------------------------------------------
-// RMSNorm on packed activations.  One workgroup per 16-row m-tile; wave w owns k-chunks
-// w, w+NW, ... (each a coalesced 1 KiB load kept in registers), row sums of squares reduce over
-// the 4 lane groups (xor 16, 32) and then over waves through LDS.
+// Stand-alone RMSNorm on packed activations (the decode loop uses the GEMM-fused form; this one
+// serves the unfused call sites and the per-kernel parity tests).  One workgroup per 16-row
+// m-tile; wave w owns k-chunks w, w+NW, ... (each a coalesced 1 KiB load kept in registers; all
+// loads are issued unconditionally up front, out-of-range chunks re-read the last one and are
+// masked), row sums of squares reduce over the 4 lane groups (xor 16, 32) and then over waves
+// through LDS.
 // ---------------------------------------------------------------------------------------------
-#define RMS_MAXC 16
-template <typename D>
+template <typename D, int RMS_MAXC>
 __global__ __launch_bounds__(1024) void rmsnorm_kernel(const uint4* __restrict__ hp, const void* __restrict__ w,
                                                        uint4* __restrict__ xn, int MTs, int d, float eps) {
     __shared__ float part[16][16];
     __shared__ float rinv[16];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, NW = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, NW = blockDim.x >> 6;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int mt = blockIdx.x;
     const int KCH = d / D::KC;
     uint4 v[RMS_MAXC];
+#pragma unroll
+    for (int i = 0; i < RMS_MAXC; ++i) {
+        int kc = wv + i * NW;
+        kc = kc < KCH ? kc : KCH - 1;
+        v[i] = hp[((size_t)kc * MTs + mt) * 64 + lane];
+    }
     float ss = 0.f;
 #pragma unroll
     for (int i = 0; i < RMS_MAXC; ++i) {
-        const int kc = wv + i * NW;
-        if (kc < KCH) {
-            v[i] = hp[((size_t)kc * MTs + mt) * 64 + lane];
-            float f[D::EPL];
-            D::unpack(v[i], f);
+        float f[D::EPL];
+        D::unpack(v[i], f);
+        float s1 = 0.f;
 #pragma unroll
-            for (int e = 0; e < D::EPL; ++e) ss += f[e] * f[e];
-        }
+        for (int e = 0; e < D::EPL; ++e) s1 += f[e] * f[e];
+        ss += (wv + i * NW < KCH) ? s1 : 0.f;
     }
     ss += __shfl_xor(ss, 16, 64);
     ss += __shfl_xor(ss, 32, 64);
@@ -108,16 +170,15 @@ extern "C" int lgen_rmsnorm(const void* hp, const void* weight, void* xnp, int M
     if (d % kcsz) return LGEN_ERR_BAD_ARG;
     const int KCH = d / kcsz;
     int nw = 4;
-    while (nw < 16 && nw * RMS_MAXC < KCH) nw *= 2;
-    if (nw * RMS_MAXC < KCH) return LGEN_ERR_BAD_ARG;
-    if (dtype == LGEN_BF16)
-        hipLaunchKernelGGL(rmsnorm_kernel<BF16>, dim3(MTs), dim3(64 * nw), 0, st, (const uint4*)hp, weight, (uint4*)xnp,
-                           MTs, d, eps);
-    else if (dtype == LGEN_F32)
-        hipLaunchKernelGGL(rmsnorm_kernel<F32>, dim3(MTs), dim3(64 * nw), 0, st, (const uint4*)hp, weight, (uint4*)xnp,
-                           MTs, d, eps);
-    else
-        return LGEN_ERR_BAD_ARG;
+    while (nw < 16 && nw * 4 < KCH) nw *= 2;  // ~4 chunks per wave, at most 8 (16 for very wide rows)
+    if (nw * 16 < KCH) return LGEN_ERR_BAD_ARG;
+    const bool wide = nw * 8 < KCH;
+#define LGEN_RMS(DT, C) hipLaunchKernelGGL((rmsnorm_kernel<DT, C>), dim3(MTs), dim3(64 * nw), 0, st, (const uint4*)hp, weight, \
+                                           (uint4*)xnp, MTs, d, eps)
+    if (dtype == LGEN_BF16) { if (wide) LGEN_RMS(BF16, 16); else LGEN_RMS(BF16, 8); }
+    else if (dtype == LGEN_F32) { if (wide) LGEN_RMS(F32, 16); else LGEN_RMS(F32, 8); }
+    else return LGEN_ERR_BAD_ARG;
+#undef LGEN_RMS
     LGEN_CHECK_LAUNCH();
     return 0;
 }
@@ -125,11 +186,14 @@ extern "C" int lgen_rmsnorm(const void* hp, const void* weight, void* xnp, int M
 // ---------------------------------------------------------------------------------------------
 // Decode attention.  One workgroup (4 waves) per (batch row, head).  K and V of that (b, h) are
 // contiguous [S8][hdp] streams; a wave-wide 16-byte-per-lane load covers KPL = 64/LPK keys
-// (LPK lanes per key).  Each wave walks its share of the keys in groups of 4 loads (K and V
-// issued together), keeps an online-softmax state (m, l, acc) and the four states merge through
-// LDS.  fp32 math from storage-dtype inputs, one rounding at the output (math-SDPA semantics,
-// incl. ATen's sqrt(scale) pre-scaling of both q and k).  Only kv_len = pos+1 keys are read --
-// the reference reads (and copies) all S8 slots and masks.
+// (LPK lanes per key).  Each wave walks its share of the keys in groups of ATT_CH loads of K and V
+// with the NEXT group's loads already in flight (register double buffer); the first group is
+// requested before the device-side position is even known (slots < S8 are always valid memory and
+// masked afterwards), so q, pos and the first 2 x ATT_CH KiB of K/V arrive in one latency.  Each
+// wave keeps an online-softmax state (m, l, acc) and the four states merge through LDS.  fp32 math
+// from storage-dtype inputs, one rounding at the output (math-SDPA semantics, incl. ATen's
+// sqrt(scale) pre-scaling of both q and k).  Only kv_len = pos+1 keys are read -- the reference
+// reads (and copies) all S8 slots and masks.
 // ---------------------------------------------------------------------------------------------
 struct AttnArgs {
     const void* q;       // [M][H][hdp]
@@ -143,80 +207,91 @@ struct AttnArgs {
 };
 
 #define ATT_NW 4
-#define ATT_CH 4
-template <typename D, int LPK>
-__global__ __launch_bounds__(64 * ATT_NW) void attn_decode_kernel(AttnArgs a) {
+template <typename D, int LPK, int ATT_CH>
+__global__ __launch_bounds__(64 * ATT_NW, (ATT_CH <= 2 ? 4 : 2)) void attn_decode_kernel(AttnArgs a) {
     constexpr int KPL = 64 / LPK;            // keys per wave-load
     constexpr int EPL = D::EPL;
+    constexpr int GK = ATT_CH * KPL;         // keys per group
     __shared__ float s_m[ATT_NW], s_l[ATT_NW];
     __shared__ float s_acc[ATT_NW][LPK * EPL];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
-    const int pos = *a.pos_ptr;
-    const int kvlen = pos + 1;
     const int part = lane % LPK, kin = lane / LPK;
     const size_t rowbase = ((size_t)b * a.H + h) * a.S8;
-    const uint4* kp = (const uint4*)a.kc + (rowbase * a.hdp) / EPL;
-    const uint4* vp = (const uint4*)a.vc + (rowbase * a.hdp) / EPL;
     const int lpr = a.hdp / EPL;             // 16-byte pieces per key row (== LPK)
-    float qf[EPL];
-    {
-        uint4 qv = ((const uint4*)a.q)[(((size_t)b * a.H + h) * a.hdp) / EPL + part];
-        D::unpack(qv, qf);
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) qf[e] *= a.sf;
+    const uint4* kp = (const uint4*)a.kc + rowbase * lpr + part;
+    const uint4* vp = (const uint4*)a.vc + rowbase * lpr + part;
+    const int smax = a.S8 - 1;
+
+    uint4 k0[ATT_CH], v0[ATT_CH], k1[ATT_CH], v1[ATT_CH];
+#define ATT_LOAD(KB, VB, g)                                                 \
+    {                                                                       \
+        _Pragma("unroll") for (int j = 0; j < ATT_CH; ++j) {                \
+            int kk = (g) * GK + j * KPL + kin;                              \
+            kk = kk < smax ? kk : smax;                                     \
+            KB[j] = kp[(size_t)kk * lpr];                                   \
+            VB[j] = vp[(size_t)kk * lpr];                                   \
+        }                                                                   \
     }
+    // group g of this wave: g = wv, wv + NW, ...; first group requested before pos is known
+    int g = wv;
+    const uint4 qv = ((const uint4*)a.q)[((size_t)b * a.H + h) * lpr + part];
+    ATT_LOAD(k0, v0, g);
+    const int pos = *a.pos_ptr;
+    const int kvlen = pos + 1;
+    const int ngroups = (kvlen + GK - 1) / GK;
+    float qf[EPL];
+    D::unpack(qv, qf);
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) qf[e] *= a.sf;
     const unsigned char* pm = a.mask ? a.mask + ((size_t)b * a.S8 + pos) * a.S8 : nullptr;
 
     float m_run = -1e30f, l_run = 0.f, acc[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
 
-    const int nchunks = (kvlen + KPL - 1) / KPL;
-    for (int c0 = wv * ATT_CH; c0 < nchunks; c0 += ATT_NW * ATT_CH) {
-        uint4 kv[ATT_CH], vv[ATT_CH];
-        int key[ATT_CH];
-#pragma unroll
-        for (int j = 0; j < ATT_CH; ++j) {
-            key[j] = (c0 + j) * KPL + kin;
-            int kk = key[j] < a.S8 ? key[j] : a.S8 - 1;
-            kv[j] = kp[(size_t)kk * lpr + part];
-            vv[j] = vp[(size_t)kk * lpr + part];
-        }
-        float s[ATT_CH];
-        float tmax = -1e30f;
-#pragma unroll
-        for (int j = 0; j < ATT_CH; ++j) {
-            float kf[EPL];
-            D::unpack(kv[j], kf);
-            float dot = 0.f;
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) dot = fmaf(qf[e], kf[e] * a.sf, dot);
-#pragma unroll
-            for (int o = 1; o < LPK; o <<= 1) dot += __shfl_xor(dot, o, 64);
-            bool vis = key[j] < kvlen;
-            if (pm && vis) vis = pm[key[j]] != 0;
-            s[j] = vis ? dot : -1e30f;
-            tmax = fmaxf(tmax, s[j]);
-        }
-#pragma unroll
-        for (int o = LPK; o < 64; o <<= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, o, 64));
-        const float m_new = fmaxf(m_run, tmax);
-        const float scale = expf(m_run - m_new);
-        l_run *= scale;
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) acc[e] *= scale;
-#pragma unroll
-        for (int j = 0; j < ATT_CH; ++j) {
-            const float p = s[j] > -1e29f ? expf(s[j] - m_new) : 0.f;
-            l_run += p;
-            float vf[EPL];
-            D::unpack(vv[j], vf);
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) acc[e] = fmaf(p, vf[e], acc[e]);
-        }
-        m_run = m_new;
+#define ATT_COMPUTE(KB, VB, g)                                                                     \
+    {                                                                                              \
+        float s[ATT_CH];                                                                           \
+        float tmax = -1e30f;                                                                       \
+        _Pragma("unroll") for (int j = 0; j < ATT_CH; ++j) {                                       \
+            const int key = (g) * GK + j * KPL + kin;                                              \
+            float kf[EPL];                                                                         \
+            D::unpack(KB[j], kf);                                                                  \
+            float dot = 0.f;                                                                       \
+            _Pragma("unroll") for (int e = 0; e < EPL; ++e) dot = fmaf(qf[e], kf[e] * a.sf, dot);  \
+            _Pragma("unroll") for (int o = 1; o < LPK; o <<= 1) dot += __shfl_xor(dot, o, 64);     \
+            bool vis = key < kvlen;                                                                \
+            if (pm && vis) vis = pm[key] != 0;                                                     \
+            s[j] = vis ? dot : -1e30f;                                                             \
+            tmax = fmaxf(tmax, s[j]);                                                              \
+        }                                                                                          \
+        _Pragma("unroll") for (int o = LPK; o < 64; o <<= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, o, 64)); \
+        const float m_new = fmaxf(m_run, tmax);                                                    \
+        const float scale = D::fexp(m_run - m_new);                                                \
+        l_run *= scale;                                                                            \
+        _Pragma("unroll") for (int e = 0; e < EPL; ++e) acc[e] *= scale;                           \
+        _Pragma("unroll") for (int j = 0; j < ATT_CH; ++j) {                                       \
+            const float p = s[j] > -1e29f ? D::fexp(s[j] - m_new) : 0.f;                           \
+            l_run += p;                                                                            \
+            float vf[EPL];                                                                         \
+            D::unpack(VB[j], vf);                                                                  \
+            _Pragma("unroll") for (int e = 0; e < EPL; ++e) acc[e] = fmaf(p, vf[e], acc[e]);       \
+        }                                                                                          \
+        m_run = m_new;                                                                             \
     }
+    while (g < ngroups) {
+        if (g + ATT_NW < ngroups) ATT_LOAD(k1, v1, g + ATT_NW);
+        ATT_COMPUTE(k0, v0, g);
+        g += ATT_NW;
+        if (g >= ngroups) break;
+        if (g + ATT_NW < ngroups) ATT_LOAD(k0, v0, g + ATT_NW);
+        ATT_COMPUTE(k1, v1, g);
+        g += ATT_NW;
+    }
+#undef ATT_LOAD
+#undef ATT_COMPUTE
     // combine the KPL key groups of this wave (lanes with equal `part`)
 #pragma unroll
     for (int o = LPK; o < 64; o <<= 1) {
@@ -238,7 +313,7 @@ __global__ __launch_bounds__(64 * ATT_NW) void attn_decode_kernel(AttnArgs a) {
         float L = 0.f, o = 0.f;
 #pragma unroll
         for (int i = 0; i < ATT_NW; ++i) {
-            const float f = expf(s_m[i] - M);
+            const float f = D::fexp(s_m[i] - M);
             L += s_l[i] * f;
             o += s_acc[i][t] * f;
         }
@@ -246,6 +321,11 @@ __global__ __launch_bounds__(64 * ATT_NW) void attn_decode_kernel(AttnArgs a) {
         D::st(a.out, D::xp_off(h * a.hd + t, b >> 4, b & 15, a.MTs), o);
     }
 }
+
+// variant: keys in flight per wave = 2 buffers x ATT_CH loads; 1 = default (ATT_CH 2: every workgroup of
+// a B2 x H = 1024 grid is resident at once, measured faster at every position), 0 = ATT_CH 4
+static int g_attn_variant = 1;
+extern "C" int lgen_set_attn_variant(int v) { g_attn_variant = v; return 0; }
 
 extern "C" int lgen_attn_decode(const void* q, const void* k_cache, const void* v_cache, void* out_packed,
                                 const int* pos_ptr, const unsigned char* mask, int B2, int MTs, int n_head,
@@ -255,10 +335,14 @@ extern "C" int lgen_attn_decode(const void* q, const void* k_cache, const void* 
     hipStream_t st = (hipStream_t)stream;
     const int epl = dtype == LGEN_BF16 ? 8 : 4;
     if (dtype != LGEN_BF16 && dtype != LGEN_F32) return LGEN_ERR_BAD_ARG;
-    if (hdp % epl || hd > hdp || hd > 64 * ATT_NW || B2 > MTs * 16) return LGEN_ERR_BAD_ARG;
+    if (hdp % epl || hd > hdp || hd > 64 * ATT_NW || B2 > MTs * 16 || S8 < 1) return LGEN_ERR_BAD_ARG;
     const int lpk = hdp / epl;
     dim3 grid(B2 * n_head), block(64 * ATT_NW);
-#define LGEN_ATT(DT, L) hipLaunchKernelGGL((attn_decode_kernel<DT, L>), grid, block, 0, st, a)
+#define LGEN_ATT(DT, L)                                                                              \
+    do {                                                                                             \
+        if (g_attn_variant == 1) hipLaunchKernelGGL((attn_decode_kernel<DT, L, 2>), grid, block, 0, st, a); \
+        else hipLaunchKernelGGL((attn_decode_kernel<DT, L, 4>), grid, block, 0, st, a);              \
+    } while (0)
     if (dtype == LGEN_BF16 && lpk == 8) LGEN_ATT(BF16, 8);
     else if (dtype == LGEN_BF16 && lpk == 16) LGEN_ATT(BF16, 16);
     else if (dtype == LGEN_F32 && lpk == 16) LGEN_ATT(F32, 16);

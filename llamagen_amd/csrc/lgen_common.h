@@ -20,13 +20,16 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 #define LGEN_DEV __device__ __forceinline__
 
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+
 LGEN_DEV float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
-LGEN_DEV uint16_t f2bf(float f) {  // round-to-nearest-even, NaN preserved
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
+// fp32 -> bf16, round-to-nearest-even (NaN stays NaN): the hardware v_cvt_pk_bf16_f32 of gfx950
+LGEN_DEV uint32_t f2bf2(float lo, float hi) {  // packed pair, lo in bits [15:0]
+    f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
+LGEN_DEV uint16_t f2bf(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
 LGEN_DEV float rnd_bf(float f) { return bf2f(f2bf(f)); }
 
 struct BF16 {
@@ -36,6 +39,7 @@ struct BF16 {
     static constexpr int CODE = 0;
     typedef uint16_t elem_t;
     LGEN_DEV static float rnd(float f) { return rnd_bf(f); }
+    LGEN_DEV static float fexp(float x) { return __expf(x); }  // softmax weights: bf16 output hides the 2-ulp fast exp
     LGEN_DEV static float ld(const void* p, size_t i) { return bf2f(((const uint16_t*)p)[i]); }
     LGEN_DEV static void st(void* p, size_t i, float v) { ((uint16_t*)p)[i] = f2bf(v); }
     // unpack the EPL values of one lane's 16 bytes
@@ -47,17 +51,17 @@ struct BF16 {
     }
     LGEN_DEV static uint4 pack(const float (&f)[8]) {
         uint4 u;
-        u.x = (uint32_t)f2bf(f[0]) | ((uint32_t)f2bf(f[1]) << 16);
-        u.y = (uint32_t)f2bf(f[2]) | ((uint32_t)f2bf(f[3]) << 16);
-        u.z = (uint32_t)f2bf(f[4]) | ((uint32_t)f2bf(f[5]) << 16);
-        u.w = (uint32_t)f2bf(f[6]) | ((uint32_t)f2bf(f[7]) << 16);
+        u.x = f2bf2(f[0], f[1]);
+        u.y = f2bf2(f[2], f[3]);
+        u.z = f2bf2(f[4], f[5]);
+        u.w = f2bf2(f[6], f[7]);
         return u;
     }
     // store 4 consecutive elements (8 bytes)
     LGEN_DEV static void st4(void* p, size_t i, float a, float b, float c, float d) {
         uint2 u;
-        u.x = (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
-        u.y = (uint32_t)f2bf(c) | ((uint32_t)f2bf(d) << 16);
+        u.x = f2bf2(a, b);
+        u.y = f2bf2(c, d);
         *(uint2*)((uint16_t*)p + i) = u;
     }
     LGEN_DEV static void ld4(const void* p, size_t i, float& a, float& b, float& c, float& d) {
@@ -65,9 +69,25 @@ struct BF16 {
         a = __uint_as_float(u.x << 16); b = __uint_as_float(u.x & 0xffff0000u);
         c = __uint_as_float(u.y << 16); d = __uint_as_float(u.y & 0xffff0000u);
     }
+    LGEN_DEV static void ld8(const void* p, size_t i, float (&f)[8]) {  // 8 consecutive elements, 16-byte aligned
+        unpack(*(const uint4*)((const uint16_t*)p + i), f);
+    }
     // element offset inside a packed activation buffer of (m-tile mt, lane-row r, k index)
     LGEN_DEV static size_t xp_off(int k, int mt, int r, int MTs) {
         return ((size_t)((k >> 5) * MTs + mt) * 64 + ((k >> 3) & 3) * 16 + r) * 8 + (k & 7);
+    }
+    // RMSNorm of one operand chunk (gpt.py:143-148): rnd(rnd(x * rinv) * w), 8 elements
+    LGEN_DEV static uint4 norm_chunk(const uint4& x, float ri, const uint4& w) {
+        float f[8], wf[8];
+        unpack(x, f);
+        unpack(w, wf);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = f[e] * ri;
+        const uint4 t = pack(f);
+        unpack(t, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = f[e] * wf[e];
+        return pack(f);
     }
     LGEN_DEV static f32x4_t mma(const uint4& a, const uint4& b, f32x4_t c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
@@ -82,6 +102,7 @@ struct F32 {
     static constexpr int CODE = 1;
     typedef float elem_t;
     LGEN_DEV static float rnd(float f) { return f; }
+    LGEN_DEV static float fexp(float x) { return expf(x); }
     LGEN_DEV static float ld(const void* p, size_t i) { return ((const float*)p)[i]; }
     LGEN_DEV static void st(void* p, size_t i, float v) { ((float*)p)[i] = v; }
     LGEN_DEV static void unpack(const uint4& u, float (&f)[4]) {
@@ -98,8 +119,20 @@ struct F32 {
         float4 v = *(const float4*)((const float*)p + i);
         a = v.x; b = v.y; c = v.z; d = v.w;
     }
+    LGEN_DEV static void ld8(const void* p, size_t i, float (&f)[8]) {
+        const float4 a = *(const float4*)((const float*)p + i), b = *(const float4*)((const float*)p + i + 4);
+        f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+    }
     LGEN_DEV static size_t xp_off(int k, int mt, int r, int MTs) {
         return ((size_t)((k >> 4) * MTs + mt) * 64 + ((k >> 2) & 3) * 16 + r) * 4 + (k & 3);
+    }
+    LGEN_DEV static uint4 norm_chunk(const uint4& x, float ri, const uint4& w) {
+        float f[4], wf[4];
+        unpack(x, f);
+        unpack(w, wf);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) f[e] = (f[e] * ri) * wf[e];
+        return pack(f);
     }
     LGEN_DEV static f32x4_t mma(const uint4& a, const uint4& b, f32x4_t c) {
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);

@@ -24,15 +24,22 @@ LGEN_DEV uint32_t fkey(float f) {  // ascending order-preserving map float -> ui
 
 struct SampleArgs {
     const void* logits;    // [>=B2][V] storage dtype, rows [0,B) cond, [B,2B) uncond when cfg
-    const float* noise;    // [B][V] Exp(1) draws (null when greedy)
+    const float* noise;    // Exp(1) draws of this step at noise + step*noise_stride, [B][V] (null when greedy)
+    long long noise_stride;
     int* cur_tok;          // [2B or B] token fed to the next step (both CFG halves)
     int* seq;              // [B][seq_stride] output ids, column = step
-    int* state;            // [0] = pos (advanced by 1), [1] = step (advanced by 1)
+    const int* state;      // [0] = pos, [1] = step (read only; the embed kernel of the next step advances them)
     int B, V, seq_stride, use_cfg;
     float cfg_scale, temperature, top_p;
-    int cfg_interval, top_k, greedy, advance;
+    int cfg_interval, top_k, greedy;
 };
 
+// Ownership: thread t owns the 8 consecutive vocabulary entries of slot s at i = (s*1024 + t)*8
+// (s < NS = 2): every wave-level global access is a contiguous 1 KiB (bf16 logits) / 2 KiB (fp32)
+// run, and ALL of a thread's loads (cond, uncond, noise) are issued before anything is consumed.
+// The radix-select passes in between walk the LDS copy with the bank-conflict-free stride-1024
+// ownership instead.
+#define SMP_NS 2
 template <typename D>
 __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(SampleArgs a) {
     extern __shared__ __attribute__((aligned(16))) float vals[];  // [V]
@@ -48,18 +55,42 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(SampleArgs a) {
     const bool mix = a.use_cfg && !(step > 0 && a.cfg_interval > -1 && (step - 1) > a.cfg_interval);
     const float tdiv = fmaxf(a.temperature, 1e-5f);
 
+    // 0. request everything this thread will ever read from HBM
+    float lc[SMP_NS][8], lu[SMP_NS][8], nz[SMP_NS][8];
+    bool own[SMP_NS];
+#pragma unroll
+    for (int s = 0; s < SMP_NS; ++s) {
+        const int i0 = (s * SMP_THREADS + tid) * 8;
+        own[s] = i0 < V;  // V % 8 == 0
+        const int ic = own[s] ? i0 : 0;
+        D::ld8(a.logits, (size_t)b * V + ic, lc[s]);
+        if (mix) D::ld8(a.logits, (size_t)(B + b) * V + ic, lu[s]);
+        if (!a.greedy) {
+            const float4* np = (const float4*)(a.noise + (size_t)step * a.noise_stride + (size_t)b * V + ic);
+            const float4 n0 = np[0], n1 = np[1];
+            nz[s][0] = n0.x; nz[s][1] = n0.y; nz[s][2] = n0.z; nz[s][3] = n0.w;
+            nz[s][4] = n1.x; nz[s][5] = n1.y; nz[s][6] = n1.z; nz[s][7] = n1.w;
+        }
+    }
+
     // 1. CFG mix + temperature -> LDS, row max
     float lmax = -INFINITY;
-    for (int i = tid; i < V; i += SMP_THREADS) {
-        float c = D::ld(a.logits, (size_t)b * V + i);
-        float l = c;
-        if (mix) {
-            float u = D::ld(a.logits, (size_t)(B + b) * V + i);
-            l = u + (c - u) * a.cfg_scale;
+#pragma unroll
+    for (int s = 0; s < SMP_NS; ++s) {
+        if (own[s]) {
+            float l[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float v = lc[s][e];
+                if (mix) v = lu[s][e] + (v - lu[s][e]) * a.cfg_scale;
+                v = v / tdiv;
+                l[e] = v;
+                lmax = fmaxf(lmax, v);
+            }
+            float4* vp = (float4*)(vals + (s * SMP_THREADS + tid) * 8);
+            vp[0] = make_float4(l[0], l[1], l[2], l[3]);
+            vp[1] = make_float4(l[4], l[5], l[6], l[7]);
         }
-        l = l / tdiv;
-        vals[i] = l;
-        lmax = fmaxf(lmax, l);
     }
     lmax = wave_max(lmax);
     if (lane == 0) red_f[wv] = lmax;
@@ -134,13 +165,21 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(SampleArgs a) {
         thr_key = sel_prefix;
     }
 
-    // 3. softmax over kept entries (max of kept == row max) and argmax(p / q)
+    // 3. softmax over kept entries (max of kept == row max) and argmax(p / q), on the owned slots
+    float ex[SMP_NS][8];
     float lsum = 0.f;
-    for (int i = tid; i < V; i += SMP_THREADS) {
-        const float l = vals[i];
-        const float e = fkey(l) >= thr_key ? expf(l - rmax) : 0.f;
-        vals[i] = e;
-        lsum += e;
+#pragma unroll
+    for (int s = 0; s < SMP_NS; ++s) {
+        if (own[s]) {
+            const float4* vp = (const float4*)(vals + (s * SMP_THREADS + tid) * 8);
+            const float4 a0 = vp[0], a1 = vp[1];
+            const float l[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                ex[s][e] = fkey(l[e]) >= thr_key ? expf(l[e] - rmax) : 0.f;
+                lsum += ex[s][e];
+            }
+        }
     }
     lsum = wave_sum(lsum);
     if (lane == 0) red_f[wv] = lsum;
@@ -155,10 +194,16 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(SampleArgs a) {
 
     float best = -1.f;
     int bidx = 0x7fffffff;
-    for (int i = tid; i < V; i += SMP_THREADS) {
-        const float p = vals[i] / tot;
-        const float r = a.greedy ? p : p / a.noise[(size_t)b * V + i];
-        if (r > best) { best = r; bidx = i; }  // ascending i: first maximum wins
+#pragma unroll
+    for (int s = 0; s < SMP_NS; ++s) {
+        if (own[s]) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float p = ex[s][e] / tot;
+                const float r = a.greedy ? p : p / nz[s][e];
+                if (r > best) { best = r; bidx = (s * SMP_THREADS + tid) * 8 + e; }  // ascending index: first maximum wins
+            }
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -180,21 +225,21 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(SampleArgs a) {
     }
 }
 
-// advances (pos, step) after every row has read `step`: a separate 1-thread kernel keeps the
-// sampler blocks independent of each other (no inter-workgroup ordering assumption).
+// (pos, step) += 1 outside a decode step (the decode step's embed kernel advances them itself).
 __global__ void advance_state_kernel(int* state) {
     state[0] += 1;
     state[1] += 1;
 }
 
-extern "C" int lgen_sample(const void* logits, const float* noise, int* cur_tok, int* seq, int* state, int B, int V,
-                           int seq_stride, int use_cfg, float cfg_scale, int cfg_interval, float temperature, int top_k,
-                           float top_p, int greedy, int advance, int dtype, void* stream) {
-    if (V > SMP_MAXV || V < 1 || B < 1) return LGEN_ERR_BAD_ARG;
+extern "C" int lgen_sample(const void* logits, const float* noise, long long noise_step_stride, int* cur_tok, int* seq,
+                           const int* state, int B, int V, int seq_stride, int use_cfg, float cfg_scale,
+                           int cfg_interval, float temperature, int top_k, float top_p, int greedy, int dtype,
+                           void* stream) {
+    if (V > SMP_MAXV || V < 8 || (V & 7) || B < 1) return LGEN_ERR_BAD_ARG;
     if (top_p < 1.0f) return LGEN_ERR_UNSUPPORTED;
     if (!greedy && !noise) return LGEN_ERR_BAD_ARG;
-    SampleArgs a{logits, noise, cur_tok, seq, state, B, V, seq_stride, use_cfg, cfg_scale, temperature, top_p,
-                 cfg_interval, top_k, greedy, advance};
+    SampleArgs a{logits, noise, noise_step_stride, cur_tok, seq, state, B, V, seq_stride, use_cfg, cfg_scale,
+                 temperature, top_p, cfg_interval, top_k, greedy};
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = (size_t)V * sizeof(float);
     static bool attr_set = false;
@@ -214,10 +259,6 @@ extern "C" int lgen_sample(const void* logits, const float* noise, int* cur_tok,
     else
         return LGEN_ERR_BAD_ARG;
     LGEN_CHECK_LAUNCH();
-    if (advance) {
-        hipLaunchKernelGGL(advance_state_kernel, dim3(1), dim3(1), 0, st, state);
-        LGEN_CHECK_LAUNCH();
-    }
     return 0;
 }
 

@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import math
 import os
+import weakref
 from typing import Optional
 
 import torch
@@ -58,6 +59,34 @@ def precompute_freqs_cis_2d(grid_size: int, n_elem: int, base: float, cls_token_
     fg = torch.concat([freqs[:, None, :].expand(-1, grid_size, -1), freqs[None, :, :].expand(grid_size, -1, -1)], dim=-1)
     cache = torch.stack([torch.cos(fg), torch.sin(fg)], dim=-1).flatten(0, 1)
     return torch.cat([torch.zeros(cls_token_num, n_elem // 2, 2), cache])
+
+
+class PackedWeights:
+    """MFMA-fragment-packed copies of a Transformer's parameters (see lgen.h for the layouts)."""
+
+    def __init__(self, model, dtype, sig):
+        cast = lambda p: p.detach().to(dtype)
+        self.sig, self.dtype = sig, dtype
+        self.layers = []
+        for blk in model.layers:
+            at, ff = blk.attention, blk.feed_forward
+            w1p, w3p = pack_weight(cast(ff.w1.weight)), pack_weight(cast(ff.w3.weight))
+            self.layers.append(dict(
+                an=cast(blk.attention_norm.weight).contiguous(), fn=cast(blk.ffn_norm.weight).contiguous(),
+                wqkv=pack_weight(cast(at.wqkv.weight)), wo=pack_weight(cast(at.wo.weight)),
+                w13=torch.stack([w1p, w3p], dim=1).flatten(0, 1).contiguous(), w2=pack_weight(cast(ff.w2.weight))))
+        self.norm_w = cast(model.norm.weight).contiguous()
+        self.out_w = pack_weight(cast(model.output.weight))
+        self.tok_emb = cast(model.tok_embeddings.weight).contiguous()
+        if model.model_type == "c2i":
+            self.cls_emb = cast(model.cls_embedding.embedding_table.weight).contiguous()
+        else:
+            self.fc1 = pack_weight(cast(model.cls_embedding.cap_proj.fc1.weight))
+            self.fc2 = pack_weight(cast(model.cls_embedding.cap_proj.fc2.weight))
+            self.cap_hidden = model.cls_embedding.cap_proj.fc1.weight.shape[0]
+
+
+_PACKED = weakref.WeakKeyDictionary()  # tok_embeddings module (shared by lane views) -> PackedWeights
 
 
 class DecodeEngine:
@@ -110,13 +139,20 @@ class DecodeEngine:
         self.gp = z(self.F // self.kc, mts, 64, self.epl)
         self.qbuf = z(mts * 16, self.H, self.hdp)            # row-major q (zero pad lanes stay zero)
         self.logits = z(mts * 16, self.V)                    # row-major, storage dtype (gpt.py:368)
-        self.noise = z(max_batch, self.V, dtype=torch.float32)
+        self.ssq = z(max(self.d // 16, 1), mts * 16, dtype=torch.float32)  # partial row sums of squares (fused RMSNorm)
+        self.ssq_parts = 0
+        self.noise = None            # [N][B][V] fp32 Exp(1) draws of one generate() (allocated on demand)
         self.cur_tok = z(mts * 16, dtype=torch.int32)
         self.seq = z(max_batch, S8 + 8, dtype=torch.int32)
         self.state = z(2, dtype=torch.int32)                 # [pos, step]
         self.use_mask = False  # True once causal_mask deviates from pure causal (t2i emb_masks)
         self._graphs = {}
         self._prof = None
+        # RMSNorm folded into the GEMM prologues (5 launches / layer) vs stand-alone norm kernels (7): on
+        # MI355X the stand-alone kernels win (3.4 us each, while normalising the whole activation panel
+        # redundantly in every workgroup of the consumer costs ~4 us of VALU time): off by default
+        self.fuse_norm = os.environ.get("LGEN_FUSED_NORM") == "1"
+        self.tile_override = {}      # kind ("qkv" | "wo" | "w13" | "w2" | "head") -> (mt, nt, kw)
         self._pack(model)
 
     # ---- weights --------------------------------------------------------------------------
@@ -124,26 +160,20 @@ class DecodeEngine:
         return tuple((p.data_ptr(), p._version) for p in model.parameters())
 
     def _pack(self, model):
-        dt = self.dtype
-        cast = lambda p: p.detach().to(dt)
-        self.layers = []
-        for blk in model.layers:
-            at, ff = blk.attention, blk.feed_forward
-            w1p, w3p = pack_weight(cast(ff.w1.weight)), pack_weight(cast(ff.w3.weight))
-            self.layers.append(dict(
-                an=cast(blk.attention_norm.weight).contiguous(), fn=cast(blk.ffn_norm.weight).contiguous(),
-                wqkv=pack_weight(cast(at.wqkv.weight)), wo=pack_weight(cast(at.wo.weight)),
-                w13=torch.stack([w1p, w3p], dim=1).flatten(0, 1).contiguous(), w2=pack_weight(cast(ff.w2.weight))))
-        self.norm_w = cast(model.norm.weight).contiguous()
-        self.out_w = pack_weight(cast(model.output.weight))
-        self.tok_emb = cast(model.tok_embeddings.weight).contiguous()
+        """Fragment-packed weight copies: built once per parameter set and shared by every engine (lane)
+        that serves the same parameters."""
+        sig = self._sig(model)
+        pw = _PACKED.get(model.tok_embeddings)
+        if pw is None or pw.sig != sig or pw.dtype != self.dtype:
+            pw = PackedWeights(model, self.dtype, sig)
+            _PACKED[model.tok_embeddings] = pw
+        self.pw = pw
+        self.layers, self.norm_w, self.out_w, self.tok_emb = pw.layers, pw.norm_w, pw.out_w, pw.tok_emb
         if model.model_type == "c2i":
-            self.cls_emb = cast(model.cls_embedding.embedding_table.weight).contiguous()
+            self.cls_emb = pw.cls_emb
         else:
-            self.fc1 = pack_weight(cast(model.cls_embedding.cap_proj.fc1.weight))
-            self.fc2 = pack_weight(cast(model.cls_embedding.cap_proj.fc2.weight))
-            self.cap_hidden = model.cls_embedding.cap_proj.fc1.weight.shape[0]
-        self._wsig = self._sig(model)
+            self.fc1, self.fc2, self.cap_hidden = pw.fc1, pw.fc2, pw.cap_hidden
+        self._wsig = sig
         self._graphs = {}
 
     def compatible(self, model, max_batch, S8, dtype) -> bool:
@@ -151,52 +181,67 @@ class DecodeEngine:
                 and self.dev == model.tok_embeddings.weight.device and self._wsig == self._sig(model))
 
     def reset(self, max_batch: int):
-        """What re-running setup_caches means in the reference: fresh (zero) caches, position 0."""
-        self.k_cache.zero_()
-        self.v_cache.zero_()
+        """What re-running setup_caches means in the reference: fresh caches, position 0.  The KV slabs are
+        NOT re-zeroed (3.5 GiB of stores per call at config 2): attention only ever reads slots < kv_len,
+        all of which the current call has written (causal), so stale slots are unobservable."""
         self.state.zero_()
         self.use_mask = False
         self.causal_mask.copy_(torch.tril(torch.ones(self.S8, self.S8, dtype=torch.bool, device=self.dev)))
 
     # ---- tile heuristics --------------------------------------------------------------------
-    def _tiles(self, N: int, K: int, swiglu: bool = False):
-        """(mt, nt, kw): workgroups ~ fill 256 CUs, >= 2 k-chunks per wave, <= 8 K-splitting waves."""
-        env = os.environ.get("LGEN_TILES")
+    def _tiles(self, kind: str, N: int, K: int):
+        """(mt, nt, kw) for one decode GEMM.  Measured on MI355X (tools/ubench_kernels.py, GPT-L, M = 64):
+        every kernel of the chain is latency-bound (~4-6 us), so the shape that wins is the one that puts
+        >= ~192 workgroups on the chip with the fewest dependent load rounds per wave: split the batch
+        rows over workgroups (mt < MTs) when N alone gives too few tiles (wo / w2: N/16 = 64), group
+        n-tiles (nt 2 / 4) only when there are >= 352 / 1024 of them (w1||w3, lm_head)."""
+        if kind in self.tile_override:
+            return self.tile_override[kind]
+        epi = {"qkv": L.EPI_QKV, "wo": L.EPI_RES, "w2": L.EPI_RES, "w13": L.EPI_SWIGLU, "head": L.EPI_ROWS}[kind]
+        norm = 1 if (self.fuse_norm and kind in ("qkv", "w13", "head")) else 0
         ntiles = N // 16
-        nt = 2 if (swiglu or ntiles >= 512) else 1
-        if ntiles % nt:
-            nt = 1
-        blocks = ntiles // nt
-        kch = K // self.kc
-        kw = max(1, min(8, round(2048 / blocks), kch // 2))
+        nt = 4 if ntiles >= 1024 else (2 if (kind == "w13" or ntiles >= 352) else 1)
+        while ntiles % nt:
+            nt //= 2
         mt = self.mt
-        if mt == 8 and nt > 2:
-            nt = 2
-        if mt * nt >= 16:
-            kw = min(kw, 8)
-        if env:
-            _, nt, kw = [int(v) for v in env.split(",")]
+        while mt > 1 and (ntiles // nt) * (self.MTs // mt) < 192 and self.MTs % (mt // 2) == 0:
+            mt //= 2
+        kmax = self.lib.lgen_gemm_max_kw(epi, norm, mt, nt)
+        kch = K // self.kc
+        kw = max(1, min(kmax, 16 if kch >= 64 else 8, kch // 2))
         return mt, nt, kw
 
     # ---- launches -----------------------------------------------------------------------------
-    def gemm(self, wp, xp, out, M, mts, N, K, epi, tiles=None):
-        mt, nt, kw = tiles or self._tiles(N, K, epi == L.EPI_SWIGLU)
+    def gemm(self, wp, xp, out, M, mts, N, K, epi, tiles, norm_w=None, ssq_out=None):
+        mt, nt, kw = tiles
         if mts % mt:
             mt = math.gcd(mts, mt)
-        L.check(self.lib.lgen_gemm(L.ptr(wp), L.ptr(xp), L.ptr(out), M, mts, N, K, epi, self.dt, mt, nt, kw, L.stream()),
-                "lgen_gemm")
+        L.check(self.lib.lgen_gemm(L.ptr(wp), L.ptr(xp), L.ptr(out), M, mts, N, K, epi, self.dt, mt, nt, kw,
+                                   L.ptr(norm_w), L.ptr(self.ssq) if norm_w is not None else 0, self.ssq_parts, self.eps,
+                                   L.ptr(ssq_out), L.stream()), "lgen_gemm")
 
     def _layers_and_logits(self, want_logits: bool = True):
+        """L x [attention_norm+wqkv+rope+append | attention | wo+res | ffn_norm+w1,w3+swiglu | w2+res], then
+        norm+output: 5 launches per layer (RMSNorm rides in the GEMM prologues, its statistics in the
+        epilogues of the GEMMs that produce the residual stream)."""
         lib, st, dt, M, mts = self.lib, L.stream(), self.dt, self.B2, self.MTs
         d, F, H, hd, hdp, S8 = self.d, self.F, self.H, self.hd, self.hdp, self.S8
         pos_ptr = self.state.data_ptr()
-        tq = self._tiles(3 * d, d)
+        fuse = self.fuse_norm
+        tq, to, t13, t2, th = (self._tiles("qkv", 3 * d, d), self._tiles("wo", d, d), self._tiles("w13", 2 * F, d),
+                               self._tiles("w2", d, F), self._tiles("head", self.V, d))
         pm = self.causal_mask if self.use_mask else None
+        ssq = self.ssq if fuse else None
         for i, w in enumerate(self.layers):
-            L.check(lib.lgen_rmsnorm(L.ptr(self.hp), L.ptr(w["an"]), L.ptr(self.xnp), mts, d, self.eps, dt, st), "rmsnorm")
-            L.check(lib.lgen_gemm_qkv_rope(L.ptr(w["wqkv"]), L.ptr(self.xnp), L.ptr(self.qbuf), L.ptr(self.k_cache[i]),
+            if fuse:
+                x_in, nw = self.hp, w["an"]
+            else:
+                L.check(lib.lgen_rmsnorm(L.ptr(self.hp), L.ptr(w["an"]), L.ptr(self.xnp), mts, d, self.eps, dt, st), "rmsnorm")
+                x_in, nw = self.xnp, None
+            L.check(lib.lgen_gemm_qkv_rope(L.ptr(w["wqkv"]), L.ptr(x_in), L.ptr(self.qbuf), L.ptr(self.k_cache[i]),
                                            L.ptr(self.v_cache[i]), L.ptr(self.freqs_cis), pos_ptr, M, mts, d, H, hd, hdp,
-                                           S8, dt, tq[0], tq[1], tq[2], st), "gemm_qkv_rope")
+                                           S8, dt, tq[0], tq[1], tq[2], L.ptr(nw), L.ptr(ssq), self.ssq_parts, self.eps, st),
+                    "gemm_qkv_rope")
             if self._prof is not None:  # bench.py roofline leg: HIP events on the launch stream
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -205,31 +250,49 @@ class DecodeEngine:
             if self._prof is not None:
                 e1.record()
                 self._prof["events"].append((e0, e1))
-            self.gemm(w["wo"], self.ap, self.hp, M, mts, d, d, L.EPI_RES)
-            L.check(lib.lgen_rmsnorm(L.ptr(self.hp), L.ptr(w["fn"]), L.ptr(self.xnp), mts, d, self.eps, dt, st), "rmsnorm")
-            self.gemm(w["w13"], self.xnp, self.gp, M, mts, 2 * F, d, L.EPI_SWIGLU)
-            self.gemm(w["w2"], self.gp, self.hp, M, mts, d, F, L.EPI_RES)
+            self.gemm(w["wo"], self.ap, self.hp, M, mts, d, d, L.EPI_RES, to, ssq_out=ssq)
+            self.ssq_parts = d // 16
+            if fuse:
+                x_in, nw = self.hp, w["fn"]
+            else:
+                L.check(lib.lgen_rmsnorm(L.ptr(self.hp), L.ptr(w["fn"]), L.ptr(self.xnp), mts, d, self.eps, dt, st), "rmsnorm")
+                x_in, nw = self.xnp, None
+            self.gemm(w["w13"], x_in, self.gp, M, mts, 2 * F, d, L.EPI_SWIGLU, t13, norm_w=nw)
+            self.gemm(w["w2"], self.gp, self.hp, M, mts, d, F, L.EPI_RES, t2, ssq_out=ssq)
         if want_logits:
-            L.check(lib.lgen_rmsnorm(L.ptr(self.hp), L.ptr(self.norm_w), L.ptr(self.xnp), mts, d, self.eps, dt, st), "rmsnorm")
-            self.gemm(self.out_w, self.xnp, self.logits, M, mts, self.V, d, L.EPI_ROWS)
+            if fuse:
+                x_in, nw = self.hp, self.norm_w
+            else:
+                L.check(lib.lgen_rmsnorm(L.ptr(self.hp), L.ptr(self.norm_w), L.ptr(self.xnp), mts, d, self.eps, dt, st), "rmsnorm")
+                x_in, nw = self.xnp, None
+            self.gemm(self.out_w, x_in, self.logits, M, mts, self.V, d, L.EPI_ROWS, th, norm_w=nw)
 
-    def _embed(self, table, idx):
-        L.check(self.lib.lgen_embed_pack(L.ptr(table), L.ptr(idx), L.ptr(self.hp), self.B2, self.MTs, self.d,
-                                         table.shape[0], self.dt, L.stream()), "embed_pack")
+    def _embed(self, table, idx, advance: bool = False):
+        L.check(self.lib.lgen_embed_pack(L.ptr(table), L.ptr(idx), L.ptr(self.hp), L.ptr(self.ssq) if self.fuse_norm else 0,
+                                         L.ptr(self.state) if advance else 0, self.B2, self.MTs, self.d, table.shape[0],
+                                         self.dt, L.stream()), "embed_pack")
+        self.ssq_parts = self.d // self.kc
 
-    def _sample(self, B, sp, advance=1):
+    def _set_residual(self, rows: torch.Tensor):
+        """Residual stream <- given rows [B2, d] (t2i prefix tokens from the CaptionEmbedder MLP)."""
+        self.hp.copy_(pack_act(rows.contiguous(), self.MTs).view_as(self.hp))
+        if self.fuse_norm:
+            L.check(self.lib.lgen_ssq_pack(L.ptr(self.hp), L.ptr(self.ssq), self.MTs, self.d, self.dt, L.stream()), "ssq_pack")
+        self.ssq_parts = self.d // self.kc
+
+    def _sample(self, B, sp):
+        """CFG mix + top-k + softmax + argmax(p/q) for the token at step = state[1]; q = noise[step]."""
         greedy = 0 if sp["sample_logits"] else 1
-        if not greedy:
-            self.noise[:B].exponential_(1.0) if sp.get("_noise") is None else self.noise[:B].copy_(sp["_noise"])
-        L.check(self.lib.lgen_sample(L.ptr(self.logits), L.ptr(self.noise), L.ptr(self.cur_tok), L.ptr(self.seq),
-                                     L.ptr(self.state), B, self.V, self.seq.shape[1], 1 if sp["use_cfg"] else 0,
-                                     float(sp["cfg_scale"]), int(sp["cfg_interval"]), float(sp["temperature"]),
-                                     int(sp["top_k"]), float(sp["top_p"]), greedy, advance, self.dt, L.stream()),
-                "lgen_sample")
+        stride = B * self.V if not greedy else 0
+        L.check(self.lib.lgen_sample(L.ptr(self.logits), 0 if greedy else L.ptr(self.noise), stride, L.ptr(self.cur_tok),
+                                     L.ptr(self.seq), L.ptr(self.state), B, self.V, self.seq.shape[1],
+                                     1 if sp["use_cfg"] else 0, float(sp["cfg_scale"]), int(sp["cfg_interval"]),
+                                     float(sp["temperature"]), int(sp["top_k"]), float(sp["top_p"]), greedy, self.dt,
+                                     L.stream()), "lgen_sample")
 
     def decode_step(self, B, sp):
-        """One KV-cached decode step: embed(cur_tok) -> L blocks -> logits -> sample -> advance."""
-        self._embed(self.tok_emb, self.cur_tok)
+        """One KV-cached decode step: advance (pos, step); embed(cur_tok) -> L blocks -> logits -> sample."""
+        self._embed(self.tok_emb, self.cur_tok, advance=True)
         self._layers_and_logits()
         self._sample(B, sp)
 
@@ -244,13 +307,39 @@ class DecodeEngine:
         hid = torch.zeros(self.cap_hidden // self.kc, mts, 64, self.epl, dtype=self.dtype, device=self.dev)
         out = torch.zeros(mts * 16, self.d, dtype=self.dtype, device=self.dev)
         mt = 8 if mts % 8 == 0 else mts
-        self.gemm(self.fc1, xp, hid, B2 * T, mts, self.cap_hidden, C, L.EPI_GELU, tiles=(mt, 1, 1))
-        self.gemm(self.fc2, hid, out, B2 * T, mts, self.d, self.cap_hidden, L.EPI_ROWS, tiles=(mt, 1, 1))
+        self.gemm(self.fc1, xp, hid, B2 * T, mts, self.cap_hidden, C, L.EPI_GELU, (mt, 1, 1))
+        self.gemm(self.fc2, hid, out, B2 * T, mts, self.d, self.cap_hidden, L.EPI_ROWS, (mt, 1, 1))
         return out[: B2 * T].view(B2, T, self.d)
+
+    # ---- Exp(1) noise: what torch.multinomial draws, one [B, V] fp32 exponential_ per sampled token ----
+    def _noise_begin(self, N, B, noise_seq):
+        """noise[i] feeds the sampler of step i.  Injected (tests) or drawn from the device's default
+        generator in the reference's order -- N separate [B, V] exponential_ calls -- up front on the
+        calling stream (N x ~5 us, < 1 % of a generate()), so that no RNG launch sits inside the captured
+        decode step.  (A side stream would overlap it, but HIP maps streams onto 4 hardware queues and a
+        lane's side stream then queues behind another lane's whole decode loop.)"""
+        if self.noise is None or self.noise.shape[0] < N or self.noise.shape[1] != B:
+            self.noise = torch.empty(N, B, self.V, dtype=torch.float32, device=self.dev)
+        if noise_seq is not None:
+            self.noise[:N].copy_(noise_seq[:N].to(self.dev))
+            return
+        for j in range(N):
+            self.noise[j].exponential_(1.0)
 
     # ---- the generate() loop ---------------------------------------------------------------
     def generate(self, model, cond_combined, B, max_new_tokens, emb_masks, sp):
         """prefill + (N-1) decode steps; returns int32 [B, N].  sp: sampling parameter dict."""
+        it = self.generate_iter(model, cond_combined, B, max_new_tokens, emb_masks, sp)
+        while True:
+            try:
+                next(it)
+            except StopIteration as stop:
+                return stop.value
+
+    def generate_iter(self, model, cond_combined, B, max_new_tokens, emb_masks, sp):
+        """Generator form of generate(): yields after every enqueued decode step (nothing waits for the GPU),
+        so that a scheduler can interleave the host-side submission of several in-flight batches
+        (llamagen_amd/pipeline.py); the int32 [B, N] result is the generator's return value."""
         N = max_new_tokens
         T = 1 if model.model_type == "c2i" else cond_combined.shape[1]
         self._prof = getattr(model, "_prof", None)
@@ -261,12 +350,10 @@ class DecodeEngine:
             cm |= torch.eye(self.S8, dtype=torch.bool, device=self.dev)
             self.use_mask = True
         noise_seq = sp.pop("_noise_seq", None)
-
-        def nz(i):
-            sp["_noise"] = None if noise_seq is None else noise_seq[i].to(self.dev)
-
-        # ---- prefill (generate.py:77-86)
-        nz(0)
+        sampling = bool(sp["sample_logits"])
+        if sampling:
+            self._noise_begin(N, B, noise_seq)
+        # ---- prefill (generate.py:77-86): state = (pos, step) = (T-1, 0) when the first token is sampled
         if model.model_type == "c2i":
             self._embed(self.cls_emb, cond_combined.to(torch.int32).contiguous())
             self._layers_and_logits()
@@ -274,21 +361,23 @@ class DecodeEngine:
             emb = self.caption_embed(cond_combined)
             for t in range(T):  # causal prefix, one position at a time (same math as the batched prefill)
                 self.state[0] = t
-                self.hp.copy_(pack_act(emb[:, t].contiguous(), self.MTs).view_as(self.hp))
+                self._set_residual(emb[:, t])
                 self._layers_and_logits(want_logits=(t == T - 1))
-        self._sample(B, sp)  # -> state = [T, 1]
-        # ---- decode (generate.py:105-123)
-        key = (B, self.use_mask, sp["use_cfg"], sp["cfg_scale"], sp["cfg_interval"], sp["temperature"], sp["top_k"], sp["top_p"],
-               sp["sample_logits"])
-        use_graph = noise_seq is None and os.environ.get("LGEN_NO_GRAPH") is None and N > 3
+        self._sample(B, sp)
+        yield 0
+        # ---- decode (generate.py:105-123): every step first advances (pos, step)
+        key = (B, N, self.use_mask, self.fuse_norm, tuple(sorted(self.tile_override.items())), sp["use_cfg"], sp["cfg_scale"],
+               sp["cfg_interval"], sp["temperature"], sp["top_k"], sp["top_p"], sp["sample_logits"],
+               self.noise.data_ptr() if sampling else 0)
+        use_graph = os.environ.get("LGEN_NO_GRAPH") is None and N > 3
         i = 1
         if use_graph:
             if i < N:  # first decode step eagerly (also warms every kernel before capture)
-                nz(i)
                 self.decode_step(B, sp)
                 i += 1
+                yield i - 1
             g = self._graphs.get(key)
-            if g is None:
+            if g is None:  # capture only records the step (on the current stream); nothing executes here
                 g = torch.cuda.CUDAGraph()
                 torch.cuda.synchronize()
                 with torch.cuda.graph(g):
@@ -297,11 +386,12 @@ class DecodeEngine:
             while i < N:
                 g.replay()
                 i += 1
+                yield i - 1
         else:
             while i < N:
-                nz(i)
                 self.decode_step(B, sp)
                 i += 1
+                yield i - 1
         return self.seq[:B, :N].clone()
 
     # ---- Transformer.forward inference branches (gpt.py:347-368) ---------------------------------
@@ -324,7 +414,7 @@ class DecodeEngine:
         for j, p in enumerate(pos):
             self.state[0] = p
             if embs is not None:
-                self.hp.copy_(pack_act(embs[:, j].contiguous(), self.MTs).view_as(self.hp))
+                self._set_residual(embs[:, j])
             elif cond_idx is not None:
                 self._embed(self.cls_emb, rows)
             else:

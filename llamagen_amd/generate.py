@@ -14,6 +14,19 @@ import torch
 
 @torch.no_grad()
 def generate(model, cond, max_new_tokens, emb_masks=None, cfg_scale=1.0, cfg_interval=-1, **sampling_kwargs):
+    """Drop-in generate(): runs the step generator below to completion on the current stream."""
+    it = generate_iter(model, cond, max_new_tokens, emb_masks, cfg_scale, cfg_interval, **sampling_kwargs)
+    while True:
+        try:
+            next(it)
+        except StopIteration as stop:
+            return stop.value
+
+
+def generate_iter(model, cond, max_new_tokens, emb_masks=None, cfg_scale=1.0, cfg_interval=-1, **sampling_kwargs):
+    """Same arguments as generate(); a generator that yields after every enqueued decode step and returns
+    the int32 [B, N] ids (StopIteration.value).  Call it (and every next()) with the lane's stream current
+    and under torch.no_grad()."""
     temperature = sampling_kwargs.pop("temperature", 1.0)
     top_k = sampling_kwargs.pop("top_k", 0)
     top_p = sampling_kwargs.pop("top_p", 1.0)
@@ -56,4 +69,4 @@ def generate(model, cond, max_new_tokens, emb_masks=None, cfg_scale=1.0, cfg_int
               sample_logits=bool(sample_logits))
     if noise_seq is not None:
         sp["_noise_seq"] = noise_seq
-    return model._engine.generate(model, cond_combined, max_batch_size, max_new_tokens, masks, sp)
+    return (yield from model._engine.generate_iter(model, cond_combined, max_batch_size, max_new_tokens, masks, sp))

@@ -214,6 +214,17 @@ class Transformer(nn.Module):
             raise RuntimeError("call setup_caches() before forward (gpt.py:316)")
         return self._engine.forward(self, idx, cond_idx, input_pos), None
 
+    def lane_view(self) -> "Transformer":
+        """A second handle on the SAME parameters with its own decode state (KV slabs, workspaces, captured
+        graph): what a concurrent in-flight batch on another HIP stream runs on (llamagen_amd/pipeline.py)."""
+        import copy
+        v = copy.copy(self)  # shallow: shares _parameters / _modules / _buffers
+        v._engine = None
+        v.causal_mask = None
+        v.freqs_cis = None
+        v.max_batch_size = v.max_seq_length = -1
+        return v
+
     def get_fsdp_wrap_module_list(self) -> List[nn.Module]:
         return list(self.layers)
 

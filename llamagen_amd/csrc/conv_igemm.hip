@@ -13,8 +13,10 @@
 //
 // Tiling: workgroup = 4 waves, BM = WMW*JM*16 pixels x BN = WNW*JN*16 output channels, K-step =
 // one tap x 32 input channels.  The pixel tile is 128 consecutive NHWC pixels of one image; the
-// nine taps re-read shifted rows through L2.  Global -> registers -> LDS double buffer (loads for
-// step s+1 are issued before the MFMAs of step s, written after them; one barrier per step).  LDS
+// nine taps re-read shifted rows through L2.  Global -> registers -> LDS double buffer with TWO
+// register staging sets (loads for step s+2 are issued before the MFMAs of step s and written to
+// LDS after the MFMAs of step s+1; one barrier per step; measured: 70 % of wave cycles were spent
+// waiting on memory with a one-step prefetch distance).  LDS
 // tiles are [rows][32] bf16 with a 16-byte-slot XOR swizzle that makes both the staging
 // `ds_write_b128` and the fragment `ds_read_b128` conflict-free for the 16x16x32 operand layout.
 // The weight tile is the MFMA A operand and the pixel tile the B operand, so a lane ends up with
@@ -35,12 +37,13 @@ struct IgemmArgs {
 
 LGEN_DEV int swz(int row, int seg) { return row * 64 + ((seg ^ ((row >> 2) & 2)) << 4); }  // byte offset in a [rows][32]bf16 tile
 
-template <int JN, int JM, int WNW>
+template <int JN, int JM, int WNW, bool DS>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
     constexpr int WMW = 4 / WNW;
     constexpr int BM = WMW * JM * 16, BN = WNW * JN * 16;
     constexpr int A_IT = (BM * 4 + 255) / 256, B_IT = (BN * 4 + 255) / 256;
     constexpr int STAGE = (BM + BN) * 64 * 2;  // bytes: (pixel tile + weight tile) x (hi, lo)
+    constexpr bool A_FULL = A_IT * 256 == BM * 4, B_FULL = B_IT * 256 == BN * 4;  // every thread stages every slot
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int t = threadIdx.x, lane = t & 63;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -70,51 +73,57 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
     const int nsteps = taps * kchunks;
     const int pad = a.ks >> 1;
 
-    uint4 ra_hi[A_IT], ra_lo[A_IT], rb_hi[B_IT], rb_lo[B_IT];
-    auto gload = [&](int step) {
-        const int tap = step / kchunks, kc = step - tap * kchunks;
-        const int dy = tap / a.ks - pad, dx = tap % a.ks - pad;
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            const int idx = t + i * 256;
-            int sy = apy[i] + dy, sx = apx[i] + dx;
-            const bool ok = apv[i] && sy >= 0 && sy < a.H && sx >= 0 && sx < a.W;
-            sy >>= a.ups; sx >>= a.ups;
-            const size_t off = (((size_t)sy * Ws + sx) * a.Cin + kc * 32 + (idx & 3) * 8);
-            ra_hi[i] = ok ? *(const uint4*)(ahi + off) : make_uint4(0, 0, 0, 0);
-            ra_lo[i] = ok ? *(const uint4*)(alo + off) : make_uint4(0, 0, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < B_IT; ++i) {
-            const int idx = t + i * 256;
-            if (idx < BN * 4) {
-                const size_t off = (((size_t)tap * a.Npad + n0 + (idx >> 2)) * a.Cin + kc * 32 + (idx & 3) * 8);
-                rb_hi[i] = *(const uint4*)(whi + off);
-                rb_lo[i] = *(const uint4*)(wlo + off);
-            }
-        }
-    };
-    auto lstore = [&](int buf) {
-        unsigned char* base = smem + buf * STAGE;
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            const int idx = t + i * 256;
-            if (idx < BM * 4) {
-                const int o = swz(idx >> 2, idx & 3);
-                *(uint4*)(base + o) = ra_hi[i];
-                *(uint4*)(base + BM * 64 + o) = ra_lo[i];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < B_IT; ++i) {
-            const int idx = t + i * 256;
-            if (idx < BN * 4) {
-                const int o = swz(idx >> 2, idx & 3);
-                *(uint4*)(base + BM * 128 + o) = rb_hi[i];
-                *(uint4*)(base + BM * 128 + BN * 64 + o) = rb_lo[i];
-            }
-        }
-    };
+    // Two register staging sets: the loads of step s+2 are issued while step s computes and are written
+    // to LDS one iteration later, so every global load has two compute phases to land.  All loads are
+    // UNCONDITIONAL (clamped to a valid address; border / tail lanes are zeroed when the registers are
+    // written to LDS): a per-lane "load or zero" select makes hipcc branch around each load and drain
+    // vmcnt per element.
+    uint4 s0_ah[A_IT], s0_al[A_IT], s0_bh[B_IT], s0_bl[B_IT], s1_ah[A_IT], s1_al[A_IT], s1_bh[B_IT], s1_bl[B_IT];
+    bool s0_ok[A_IT], s1_ok[A_IT];
+#define IG_GLOAD(step_, P)                                                                              \
+    {                                                                                                   \
+        const int st_ = (step_) < nsteps ? (step_) : nsteps - 1; /* tail: harmless re-load */           \
+        const int tap = st_ / kchunks, kc = st_ - tap * kchunks;                                        \
+        const int dy = tap / a.ks - pad, dx = tap % a.ks - pad;                                         \
+        _Pragma("unroll") for (int i = 0; i < A_IT; ++i) {                                              \
+            const int idx = t + i * 256;                                                                \
+            int sy = apy[i] + dy, sx = apx[i] + dx;                                                     \
+            P##ok[i] = apv[i] && sy >= 0 && sy < a.H && sx >= 0 && sx < a.W;                            \
+            sy = P##ok[i] ? sy >> a.ups : 0;                                                            \
+            sx = P##ok[i] ? sx >> a.ups : 0;                                                            \
+            const size_t off = (((size_t)sy * Ws + sx) * a.Cin + kc * 32 + (idx & 3) * 8);              \
+            P##ah[i] = *(const uint4*)(ahi + off);                                                      \
+            P##al[i] = *(const uint4*)(alo + off);                                                      \
+        }                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < B_IT; ++i) {                                              \
+            const int idx = t + i * 256;                                                                \
+            const int row = idx < BN * 4 ? (idx >> 2) : 0;                                              \
+            const size_t off = (((size_t)tap * a.Npad + n0 + row) * a.Cin + kc * 32 + (idx & 3) * 8);   \
+            P##bh[i] = *(const uint4*)(whi + off);                                                      \
+            P##bl[i] = *(const uint4*)(wlo + off);                                                      \
+        }                                                                                               \
+    }
+#define IG_LSTORE(buf_, P)                                                                              \
+    {                                                                                                   \
+        unsigned char* base = smem + (buf_) * STAGE;                                                    \
+        _Pragma("unroll") for (int i = 0; i < A_IT; ++i) {                                              \
+            const int idx = t + i * 256;                                                                \
+            if (A_FULL || idx < BM * 4) {                                                               \
+                const int o = swz(idx >> 2, idx & 3);                                                   \
+                const unsigned m_ = P##ok[i] ? 0xffffffffu : 0u; /* scalar mask: no lvalue select */   \
+                *(uint4*)(base + o) = make_uint4(P##ah[i].x & m_, P##ah[i].y & m_, P##ah[i].z & m_, P##ah[i].w & m_); \
+                *(uint4*)(base + BM * 64 + o) = make_uint4(P##al[i].x & m_, P##al[i].y & m_, P##al[i].z & m_, P##al[i].w & m_); \
+            }                                                                                           \
+        }                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < B_IT; ++i) {                                              \
+            const int idx = t + i * 256;                                                                \
+            if (B_FULL || idx < BN * 4) {                                                               \
+                const int o = swz(idx >> 2, idx & 3);                                                   \
+                *(uint4*)(base + BM * 128 + o) = P##bh[i];                                              \
+                *(uint4*)(base + BM * 128 + BN * 64 + o) = P##bl[i];                                    \
+            }                                                                                           \
+        }                                                                                               \
+    }
 
     f32x4_t acc[JN][JM];
 #pragma unroll
@@ -122,15 +131,10 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
 #pragma unroll
         for (int i = 0; i < JM; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    gload(0);
-    lstore(0);
-    __syncthreads();
     const int fr = lane & 15, fg = lane >> 4;
-    for (int step = 0; step < nsteps; ++step) {
-        const int buf = step & 1;
-        if (step + 1 < nsteps) gload(step + 1);
+    auto compute = [&](int buf) {
         const unsigned char* base = smem + buf * STAGE;
-        uint4 phi[JM], plo[JM], whi_f[JN], wlo_f[JN];
+        uint4 phi[JM], plo[JM];
 #pragma unroll
         for (int i = 0; i < JM; ++i) {
             const int o = swz((wm * JM + i) * 16 + fr, fg);
@@ -138,22 +142,44 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
             plo[i] = *(const uint4*)(base + BM * 64 + o);
         }
 #pragma unroll
-        for (int j = 0; j < JN; ++j) {
+        for (int j = 0; j < JN; ++j) {  // weight fragments one n-tile at a time (register pressure)
             const int o = swz((wn * JN + j) * 16 + fr, fg);
-            whi_f[j] = *(const uint4*)(base + BM * 128 + o);
-            wlo_f[j] = *(const uint4*)(base + BM * 128 + BN * 64 + o);
-        }
-#pragma unroll
-        for (int j = 0; j < JN; ++j)
+            const uint4 wh = *(const uint4*)(base + BM * 128 + o);
+            const uint4 wl = *(const uint4*)(base + BM * 128 + BN * 64 + o);
 #pragma unroll
             for (int i = 0; i < JM; ++i) {
-                acc[j][i] = BF16::mma(wlo_f[j], phi[i], acc[j][i]);
-                acc[j][i] = BF16::mma(whi_f[j], plo[i], acc[j][i]);
-                acc[j][i] = BF16::mma(whi_f[j], phi[i], acc[j][i]);
+                acc[j][i] = BF16::mma(wl, phi[i], acc[j][i]);
+                acc[j][i] = BF16::mma(wh, plo[i], acc[j][i]);
+                acc[j][i] = BF16::mma(wh, phi[i], acc[j][i]);
             }
-        if (step + 1 < nsteps) lstore(buf ^ 1);
+        }
+    };
+
+    IG_GLOAD(0, s0_);
+    if constexpr (DS) IG_GLOAD(1, s1_);
+    IG_LSTORE(0, s0_);
+    __syncthreads();
+    if constexpr (!DS) {  // one staging set: loads of step s+1 fly during the MFMAs of step s only
+        for (int step = 0; step < nsteps; ++step) {
+            IG_GLOAD(step + 1, s0_);
+            compute(step & 1);
+            IG_LSTORE((step & 1) ^ 1, s0_);
+            __syncthreads();
+        }
+    } else
+    for (int step = 0; step < nsteps; step += 2) {
+        IG_GLOAD(step + 2, s0_);   // set 0 (step) is already in LDS buffer 0
+        compute(0);
+        IG_LSTORE(1, s1_);         // step + 1, requested one iteration ago
+        __syncthreads();
+        if (step + 1 >= nsteps) break;
+        IG_GLOAD(step + 3, s1_);
+        compute(1);
+        IG_LSTORE(0, s0_);         // step + 2
         __syncthreads();
     }
+#undef IG_GLOAD
+#undef IG_LSTORE
 
     // epilogue: lane holds out channels n = nb + fg*4 + {0..3} of pixel p = pb + fr
     float* outb = a.out + (size_t)b * a.o_bstride;
@@ -190,22 +216,26 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
     }
 }
 
-template <int JN, int JM, int WNW>
+template <int JN, int JM, int WNW, bool DS>
 static int launch_igemm(const IgemmArgs& a, int B, hipStream_t st) {
     constexpr int BM = (4 / WNW) * JM * 16, BN = WNW * JN * 16;
     const size_t lds = 2 * (size_t)(BM + BN) * 64 * 2;
     if (a.Npad % BN) return LGEN_ERR_BAD_ARG;
     static bool attr = false;
     if (!attr && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<JN, JM, WNW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<JN, JM, WNW, DS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr = true;
     }
     dim3 grid((a.H * a.W + BM - 1) / BM, a.Npad / BN, B);
-    hipLaunchKernelGGL((igemm_kernel<JN, JM, WNW>), grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((igemm_kernel<JN, JM, WNW, DS>), grid, dim3(256), lds, st, a);
     LGEN_CHECK_LAUNCH();
     return 0;
 }
+
+// tuning knob (tools/): 0 = 128x128 tile, one staging set; 1 = 128x128, two staging sets; 2 = 128x64 tiles, two sets
+static int g_igemm_variant = 0;
+extern "C" int lgen_set_igemm_variant(int v) { g_igemm_variant = v; return 0; }
 
 extern "C" int lgen_conv_igemm(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo, const float* bias,
                                const float* res, float* out, int B, int H, int W, int Cin, int Cout, int Npad, int ksize,
@@ -217,7 +247,9 @@ extern "C" int lgen_conv_igemm(const void* a_hi, const void* a_lo, const void* w
                 H, W, Cin, Cout, Npad, ksize, upsample ? 1 : 0, out_nchw,
                 (long long)(H >> (upsample ? 1 : 0)) * (W >> (upsample ? 1 : 0)) * Cin, w_bstride, (long long)H * W * Cout, alpha};
     hipStream_t st = (hipStream_t)stream;
-    if (Npad % 128 == 0) return launch_igemm<4, 4, 2>(a, B, st);   // 128 px x 128 ch
-    if (Npad % 64 == 0) return launch_igemm<4, 2, 1>(a, B, st);    // 128 px x 64 ch
-    return launch_igemm<1, 2, 1>(a, B, st);                        // 128 px x 16 ch (conv_out, Cout = 3)
+    if (g_igemm_variant == 2 && Npad % 64 == 0) return launch_igemm<4, 2, 1, true>(a, B, st);
+    if (Npad % 128 == 0)                                            // 128 px x 128 ch
+        return g_igemm_variant == 1 ? launch_igemm<4, 4, 2, true>(a, B, st) : launch_igemm<4, 4, 2, false>(a, B, st);
+    if (Npad % 64 == 0) return launch_igemm<4, 2, 1, true>(a, B, st);    // 128 px x 64 ch
+    return launch_igemm<1, 2, 1, true>(a, B, st);                        // 128 px x 16 ch (conv_out, Cout = 3)
 }

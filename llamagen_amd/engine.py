@@ -192,7 +192,7 @@ class DecodeEngine:
     def _tiles(self, kind: str, N: int, K: int):
         """(mt, nt, kw) for one decode GEMM.  Measured on MI355X (tools/ubench_kernels.py, GPT-L, M = 64):
         every kernel of the chain is latency-bound (~4-6 us), so the shape that wins is the one that puts
-        >= ~192 workgroups on the chip with the fewest dependent load rounds per wave: split the batch
+        >= ~160 workgroups on the chip with the fewest dependent load rounds per wave: split the batch
         rows over workgroups (mt < MTs) when N alone gives too few tiles (wo / w2: N/16 = 64), group
         n-tiles (nt 2 / 4) only when there are >= 352 / 1024 of them (w1||w3, lm_head)."""
         if kind in self.tile_override:
@@ -204,7 +204,7 @@ class DecodeEngine:
         while ntiles % nt:
             nt //= 2
         mt = self.mt
-        while mt > 1 and (ntiles // nt) * (self.MTs // mt) < 192 and self.MTs % (mt // 2) == 0:
+        while mt > 1 and (ntiles // nt) * (self.MTs // mt) < 160 and self.MTs % (mt // 2) == 0:
             mt //= 2
         kmax = self.lib.lgen_gemm_max_kw(epi, norm, mt, nt)
         kch = K // self.kc

@@ -1,0 +1,121 @@
+// Shared by the skinny-GEMM translation units (gemm_skinny.hip, gemm_normpre.hip): kernel arguments,
+// early epilogue operand fetch and the fused epilogues.  See gemm_skinny.hip for the design notes.
+#pragma once
+#include "lgen_common.h"
+#include "../../include/lgen.h"
+
+enum { EPI_ROWS = 0, EPI_PACKED = 1, EPI_GELU = 2, EPI_RES = 3, EPI_SWIGLU = 4, EPI_QKV = 5 };
+
+struct GemmArgs {
+    const uint4* wp;     // packed weights [N/16][KCH][64] x 16 B
+    const uint4* xp;     // packed activations [KCH][MTs][64] x 16 B
+    void* out;           // EPI_ROWS: [M][N]; packed epilogues: XP of width N (or N/2 for SWIGLU); QKV: q rows
+    void* kc;            // QKV: k cache
+    void* vc;            // QKV: v cache
+    const float* freqs;  // QKV: [P][hd/2][2] fp32 (cos, sin)
+    const int* pos_ptr;  // QKV: device scalar, position of this token
+    const uint4* nw;     // NORM: RMSNorm weight [K] storage dtype
+    const float* ssq_in; // NORM: [parts][MTs*16] partial sums of squares of the x rows
+    float* ssq_out;      // RES: [N/16][MTs*16] partial sums of squares of the new rows (nullable)
+    int N, KCH, MTs, M;
+    int d, hd, hdp, H, S8;
+    int parts;
+    float eps, inv_k;
+};
+
+LGEN_DEV float silu_f(float x) { return x / (1.0f + expf(-x)); }
+LGEN_DEV float gelu_tanh_f(float x) {
+    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+    float inner = k0 * (x + k1 * x * x * x);
+    return 0.5f * x * (1.0f + tanhf(inner));
+}
+
+// memory operands of an epilogue, requested early: RES -> the residual tile, QKV -> RoPE (cos, sin) x 2
+template <typename D, int EPI>
+LGEN_DEV uint4 epi_prefetch(const GemmArgs& a, int nt, int mt, int lane, int pos) {
+    uint4 aux = make_uint4(0, 0, 0, 0);
+    const int r = lane & 15, g = lane >> 4;
+    const int n = nt * 16 + g * 4;
+    if constexpr (EPI == EPI_RES) {
+        const size_t o = D::xp_off(n, mt, r, a.MTs);
+        if constexpr (D::ESZ == 2) {
+            const uint2 v = *(const uint2*)((const uint16_t*)a.out + o);
+            aux.x = v.x; aux.y = v.y;
+        } else {
+            aux = *(const uint4*)((const float*)a.out + o);
+        }
+    } else if constexpr (EPI == EPI_QKV) {
+        const int sec = n / a.d;
+        if (sec < 2) {
+            const int c = n - sec * a.d;
+            const int dd = c % a.hd;
+            aux = *(const uint4*)(a.freqs + ((size_t)pos * (a.hd >> 1) + (dd >> 1)) * 2);
+        }
+    }
+    return aux;
+}
+
+// one 16x16 output tile: lane (g = lane>>4, r = lane&15) holds n = nt*16 + g*4 + {0..3}, m = mt*16 + r
+template <typename D, int EPI>
+LGEN_DEV void epilogue(const GemmArgs& a, int nt, int mt, int lane, f32x4_t v, f32x4_t v2, const uint4& aux, int pos) {
+    const int r = lane & 15, g = lane >> 4;
+    const int m = mt * 16 + r;
+    const int n = nt * 16 + g * 4;
+    float x0 = D::rnd(v[0]), x1 = D::rnd(v[1]), x2 = D::rnd(v[2]), x3 = D::rnd(v[3]);  // nn.Linear output rounding
+    if constexpr (EPI == EPI_ROWS) {
+        if (m < a.M) D::st4(a.out, (size_t)m * a.N + n, x0, x1, x2, x3);
+    } else if constexpr (EPI == EPI_PACKED) {
+        D::st4(a.out, D::xp_off(n, mt, r, a.MTs), x0, x1, x2, x3);
+    } else if constexpr (EPI == EPI_GELU) {
+        D::st4(a.out, D::xp_off(n, mt, r, a.MTs), gelu_tanh_f(x0), gelu_tanh_f(x1), gelu_tanh_f(x2), gelu_tanh_f(x3));
+    } else if constexpr (EPI == EPI_RES) {
+        float h0, h1, h2, h3;
+        if constexpr (D::ESZ == 2) {
+            h0 = __uint_as_float(aux.x << 16); h1 = __uint_as_float(aux.x & 0xffff0000u);
+            h2 = __uint_as_float(aux.y << 16); h3 = __uint_as_float(aux.y & 0xffff0000u);
+        } else {
+            h0 = __uint_as_float(aux.x); h1 = __uint_as_float(aux.y);
+            h2 = __uint_as_float(aux.z); h3 = __uint_as_float(aux.w);
+        }
+        h0 = D::rnd(h0 + x0); h1 = D::rnd(h1 + x1); h2 = D::rnd(h2 + x2); h3 = D::rnd(h3 + x3);
+        D::st4(a.out, D::xp_off(n, mt, r, a.MTs), h0, h1, h2, h3);
+        if (a.ssq_out) {  // fixed-order partial of sum(h^2) over this tile's 16 columns, per row
+            float ss = ((h0 * h0 + h1 * h1) + h2 * h2) + h3 * h3;
+            ss += __shfl_xor(ss, 16, 64);
+            ss += __shfl_xor(ss, 32, 64);
+            if (lane < 16) a.ssq_out[(size_t)nt * (a.MTs * 16) + m] = ss;
+        }
+    } else if constexpr (EPI == EPI_SWIGLU) {
+        // nt is the w1 tile (even), v2 the matching w3 tile; output feature f = (nt/2)*16 + g*4
+        float y0 = D::rnd(v2[0]), y1 = D::rnd(v2[1]), y2 = D::rnd(v2[2]), y3 = D::rnd(v2[3]);
+        int f = (nt >> 1) * 16 + g * 4;
+        D::st4(a.out, D::xp_off(f, mt, r, a.MTs),
+               D::rnd(silu_f(x0)) * y0, D::rnd(silu_f(x1)) * y1, D::rnd(silu_f(x2)) * y2, D::rnd(silu_f(x3)) * y3);
+    } else if constexpr (EPI == EPI_QKV) {
+        if (m >= a.M) return;
+        const int sec = n / a.d;
+        const int c = n - sec * a.d;
+        const int head = c / a.hd;
+        const int dd = c - head * a.hd;
+        if (sec < 2) {  // 2-D RoPE on interleaved (even, odd) pairs, fp32, one rounding
+            const float fx = __uint_as_float(aux.x), fy = __uint_as_float(aux.y);
+            const float fz = __uint_as_float(aux.z), fw = __uint_as_float(aux.w);
+            float y0 = x0 * fx - x1 * fy, y1 = x1 * fx + x0 * fy;
+            float y2 = x2 * fz - x3 * fw, y3 = x3 * fz + x2 * fw;
+            x0 = y0; x1 = y1; x2 = y2; x3 = y3;
+        }
+        if (sec == 0) {
+            D::st4(a.out, ((size_t)m * a.H + head) * a.hdp + dd, x0, x1, x2, x3);
+        } else {
+            void* cache = sec == 1 ? a.kc : a.vc;
+            D::st4(cache, (((size_t)m * a.H + head) * a.S8 + pos) * a.hdp + dd, x0, x1, x2, x3);
+        }
+    }
+}
+
+template <int EPI> constexpr bool epi_has_aux() { return EPI == EPI_RES || EPI == EPI_QKV; }
+
+
+// gemm_normpre.hip: RMSNorm-fused GEMM that normalises while its weights are in flight (small K per wave);
+// returns LGEN_ERR_UNSUPPORTED when the shape is outside its envelope (caller falls back).
+int lgen_gemm_normpre_try(const GemmArgs& a, int epi, int dtype, int mt, int nt, int kw, hipStream_t st);

@@ -148,10 +148,15 @@ class DecodeEngine:
         self.use_mask = False  # True once causal_mask deviates from pure causal (t2i emb_masks)
         self._graphs = {}
         self._prof = None
-        # RMSNorm folded into the GEMM prologues (5 launches / layer) vs stand-alone norm kernels (7): on
-        # MI355X the stand-alone kernels win (3.4 us each, while normalising the whole activation panel
-        # redundantly in every workgroup of the consumer costs ~4 us of VALU time): off by default
-        self.fuse_norm = os.environ.get("LGEN_FUSED_NORM") == "1"
+        # RMSNorm folded into the consumer GEMMs (5 launches / layer instead of 7).  Pays off (-12 % step time,
+        # GPT-L) only with gemm_normpre.hip, which normalises the activation panel in registers while the
+        # weight loads are in flight and needs a wave's K range to fit in registers: bf16, d/32 = 8 waves x
+        # 3..6 chunks (GPT-B .. GPT-XXL).  Elsewhere the stand-alone 3.4 us norm kernels are faster than the
+        # generic NORM prologue (+4 us of exposed VALU work per GEMM).
+        kch = self.d // self.kc
+        auto = dtype == torch.bfloat16 and kch % 8 == 0 and 3 <= kch // 8 <= 6
+        env = os.environ.get("LGEN_FUSED_NORM")
+        self.fuse_norm = auto if env is None else env == "1"
         self.tile_override = {}      # kind ("qkv" | "wo" | "w13" | "w2" | "head") -> (mt, nt, kw)
         self._pack(model)
 
@@ -198,16 +203,24 @@ class DecodeEngine:
         if kind in self.tile_override:
             return self.tile_override[kind]
         epi = {"qkv": L.EPI_QKV, "wo": L.EPI_RES, "w2": L.EPI_RES, "w13": L.EPI_SWIGLU, "head": L.EPI_ROWS}[kind]
-        norm = 1 if (self.fuse_norm and kind in ("qkv", "w13", "head")) else 0
+        fused = self.fuse_norm and kind in ("qkv", "w13", "head")
         ntiles = N // 16
+        kch = K // self.kc
+        if fused and kch % 8 == 0 and 3 <= kch // 8 <= 6:
+            # normpre kernel: every workgroup normalises its own rows of the panel, so halve the rows per
+            # workgroup and group n-tiles instead (measured best at MTs = 4: qkv (1,4,8), w1||w3 (2,4,8))
+            mt = max(1, self.mt // (4 if kind == "qkv" else 2))
+            nt = 4
+            while ntiles % nt or (kind == "w13" and nt & 1 and nt > 1):
+                nt //= 2
+            return mt, max(nt, 2 if kind == "w13" else 1), 8
         nt = 4 if ntiles >= 1024 else (2 if (kind == "w13" or ntiles >= 352) else 1)
         while ntiles % nt:
             nt //= 2
         mt = self.mt
         while mt > 1 and (ntiles // nt) * (self.MTs // mt) < 160 and self.MTs % (mt // 2) == 0:
             mt //= 2
-        kmax = self.lib.lgen_gemm_max_kw(epi, norm, mt, nt)
-        kch = K // self.kc
+        kmax = self.lib.lgen_gemm_max_kw(epi, 1 if fused else 0, mt, nt)
         kw = max(1, min(kmax, 16 if kch >= 64 else 8, kch // 2))
         return mt, nt, kw
 

@@ -371,3 +371,41 @@ def test_generate_graph_replay_matches_oracle_on_gpu_noise(name):
     model = O.GPTOracle(oracle_cfg(case), sd, torch.float32)
     ref = O.generate(model, cond, case["n_new"], emb_masks=masks, noise_fn=lambda shape: next(it), **kw)
     np.testing.assert_array_equal(t1.cpu().numpy(), ref.numpy())
+
+
+def test_fused_norm_engine_matches_unfused_bf16():
+    """GPT-B-shaped bf16 model (d = 768: the decode loop auto-selects the RMSNorm-fused GEMMs): the logits of
+    a few teacher-forced steps must agree with the same engine running the stand-alone norm kernels to
+    bf16 resolution, and both with the oracle's."""
+    from llamagen_amd.gpt import ModelArgs, Transformer
+    from llamagen_amd.testing import synth_for_module
+    dev = _dev()
+    kw = dict(n_layer=2, n_head=12, dim=768, vocab_size=2048, block_size=16, num_classes=10, cls_token_num=1, model_type="c2i")
+    m = Transformer(ModelArgs(**kw))
+    sd = synth_for_module(m, seed=5, lin_std=0.05)
+    m.load_state_dict(sd, strict=False)
+    m = m.to(device=dev, dtype=torch.bfloat16).eval()
+    B2, steps = 6, 5
+    toks = torch.randint(0, 2048, (B2, steps), generator=torch.Generator().manual_seed(3)).to(dev)
+    cond = torch.tensor([1, 2, 3, 10, 10, 10], device=dev)
+    outs = {}
+    for fuse in (True, False):
+        m._engine = None
+        m.setup_caches(B2, 1 + steps, torch.bfloat16)
+        assert m._engine.fuse_norm  # auto rule: bf16, d/32 = 8 x 3
+        m._engine.fuse_norm = fuse
+        lg = [m(None, cond, torch.arange(0, 1, device=dev))[0][:, -1]]
+        for i in range(steps):
+            lg.append(m(toks[:, i:i + 1], None, torch.tensor([1 + i], device=dev, dtype=torch.int))[0][:, -1])
+        outs[fuse] = torch.stack(lg).float().cpu()
+    ulp = outs[False].abs().max().item() * 2.0 ** -8
+    err = (outs[True] - outs[False]).abs()
+    assert err.max().item() <= 4 * ulp and err.mean().item() <= 0.25 * ulp, (err.max().item(), err.mean().item(), ulp)
+    model = O.GPTOracle(O.GPTConfig(**kw), sd, torch.bfloat16)
+    model.setup_caches(B2, 1 + steps)
+    ref = [model.forward(None, cond.cpu(), torch.arange(0, 1))[:, -1]]
+    for i in range(steps):
+        ref.append(model.forward(toks[:, i:i + 1].cpu(), None, torch.tensor([1 + i]))[:, -1])
+    ref = torch.stack(ref).float()
+    e2 = (outs[True] - ref).abs()
+    assert e2.max().item() <= 4 * ulp and e2.mean().item() <= 0.25 * ulp, (e2.max().item(), e2.mean().item(), ulp)

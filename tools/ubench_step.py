@@ -68,32 +68,26 @@ def main(name="GPT-L", B=32, img=384, what="all"):
         return ts
 
     print("default tiles:", {k: eng._tiles(k, *nk) for k, nk in dict(qkv=(3 * d, d), wo=(d, d), w13=(2 * F, d), w2=(d, F), head=(V, d)).items()})
-    row("base (fused norm, attn variant 0)")
-    if what in ("all", "attn"):
-        L.lib().lgen_set_attn_variant(1)
-        row("attn variant 1 (CH=2, 16 waves/CU)")
-        L.lib().lgen_set_attn_variant(0)
-    if what in ("all", "base"):
-        eng.fuse_norm = False
-        row("unfused rmsnorm kernels")
-        eng.fuse_norm = True
-    if what in ("all", "gemm"):
-        mt = eng.mt
-        sweeps = {
-            "qkv": [(mt, 1, 4), (mt, 1, 8), (mt, 2, 8), (mt, 2, 4), (2, 1, 8), (1, 1, 8)],
-            "wo": [(mt, 1, 4), (mt, 1, 8), (2, 1, 8), (1, 1, 8), (2, 1, 4), (1, 1, 4)],
-            "w13": [(mt, 2, 4), (mt, 2, 8), (mt, 4, 8), (2, 2, 8), (2, 4, 8)],
-            "w2": [(mt, 1, 4), (mt, 1, 8), (2, 1, 8), (1, 1, 8), (2, 1, 4), (1, 1, 4), (1, 2, 8)],
-            "head": [(mt, 2, 4), (mt, 2, 8), (mt, 4, 8), (mt, 1, 8), (mt, 4, 4), (2, 4, 8)],
-        }
-        for kind, cfgs in sweeps.items():
-            for cfg in cfgs:
-                eng.tile_override = {kind: cfg}
-                try:
-                    row(f"{kind} tiles {cfg}")
-                except Exception as e:  # unsupported (register budget) -> skip
-                    print(f"{kind} tiles {cfg}: {type(e).__name__} {e}")
-            eng.tile_override = {}
+    # interleaved A/B (run-to-run drift on this box is several %): every config is measured in every round
+    configs = {
+        "unfused": dict(fuse=False, tiles={}),
+        "fused default": dict(fuse=True, tiles={}),
+        "fused head(2,4,8)": dict(fuse=True, tiles={"head": (2, 4, 8)}),
+        "fused head(4,4,8)": dict(fuse=True, tiles={"head": (4, 4, 8)}),
+        "fused qkv(2,4,8)": dict(fuse=True, tiles={"qkv": (2, 4, 8)}),
+        "fused qkv(1,4,8)": dict(fuse=True, tiles={"qkv": (1, 4, 8)}),
+        "fused w13(1,4,8)": dict(fuse=True, tiles={"w13": (1, 4, 8)}),
+        "fused wo(2,1,8) w2(2,1,16)": dict(fuse=True, tiles={"wo": (2, 1, 8), "w2": (2, 1, 16)}),
+    }
+    for rnd in range(2):
+        for tag, c in configs.items():
+            eng.fuse_norm = c["fuse"]
+            eng.tile_override = dict(c["tiles"])
+            try:
+                row(f"r{rnd} {tag}")
+            except Exception as e:
+                print(tag, "->", type(e).__name__, e)
+    eng.tile_override = {}
     print("max mem GB", torch.cuda.max_memory_allocated() / 2 ** 30)
 
 

@@ -8,9 +8,9 @@
 // consumption as the reference); everything else is one kernel with no host sync -- the
 // reference's boolean-mask assignment and multinomial validity checks each sync the host.
 //
-// One workgroup (1024 threads) per image row; the whole row (V <= 16384 fp32 = 64 KiB) lives in
-// LDS.  k-th largest by MSB-first radix select on order-preserving uint keys (4 passes of 8
-// bits; pass 0 uses wave-aggregated histogram updates because logits share few exponents).
+// One workgroup (1024 threads) per image row; the row (V <= 16384) lives in registers, 16 values
+// per thread.  k-th largest by a one-pass value-bin histogram + exact rank inside the critical bin
+// (MSB-first radix select on an LDS copy as the exact fallback for degenerate rows).
 #include "lgen_common.h"
 #include "../../include/lgen.h"
 
@@ -36,18 +36,90 @@ struct SampleArgs {
 
 // Ownership: thread t owns the 8 consecutive vocabulary entries of slot s at i = (s*1024 + t)*8
 // (s < NS = 2): every wave-level global access is a contiguous 1 KiB (bf16 logits) / 2 KiB (fp32)
-// run, and ALL of a thread's loads (cond, uncond, noise) are issued before anything is consumed.
-// The radix-select passes in between walk the LDS copy with the bank-conflict-free stride-1024
-// ownership instead.
+// run, ALL of a thread's loads (cond, uncond, noise) are issued before anything is consumed, and the
+// row stays in registers.
+//
+// k-th largest value (top-k threshold, ties kept): ONE histogram pass over NB = 4096 equal-width value
+// bins between the row minimum and maximum (monotone binning: a higher bin holds strictly larger
+// values), a suffix scan that finds the bin holding the k-th largest, and an exact rank among the few
+// values of that bin.  Logits are spread over many bins, so the LDS atomics rarely collide -- the
+// bit-radix select this replaces spent ~30 us in its first pass, where all values share 3-4 exponent
+// bins.  Rows the histogram cannot resolve (more than SMP_CAND values in the critical bin, e.g. constant
+// rows, or non-finite values) take the exact MSB-first radix select on an LDS copy instead.
 #define SMP_NS 2
+#define SMP_NB 4096
+#define SMP_CAND 1024
+
+// exact k-th largest key of vals[0..V) (order-preserving uint keys), 4 x 8-bit MSB-first radix passes
+LGEN_DEV uint32_t radix_kth_key(const float* vals, int V, int k, unsigned* hist, unsigned* sel /* [2] */) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) { sel[0] = 0; sel[1] = (unsigned)k; }
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        const unsigned prefix = sel[0];
+        const unsigned pmask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
+        for (int i = tid; i < V; i += SMP_THREADS) {
+            const uint32_t key = fkey(vals[i]);
+            bool act = (key & pmask) == prefix;
+            const unsigned bin = (key >> shift) & 0xffu;
+            if (pass == 0) {  // wave-aggregated: few distinct exponent bins
+                unsigned long long todo = __ballot(act);
+                while (todo) {
+                    const int leader = __ffsll((long long)todo) - 1;
+                    const unsigned lb = __shfl(bin, leader, 64);
+                    const unsigned long long same = __ballot(act && bin == lb);
+                    if (lane == leader) atomicAdd(&hist[lb], (unsigned)__popcll(same));
+                    todo &= ~same;
+                    if (bin == lb) act = false;
+                }
+            } else if (act) {
+                atomicAdd(&hist[bin], 1u);
+            }
+        }
+        __syncthreads();
+        if (wv == 0) {  // one wave scans the 256 bins from the top (4 bins per lane)
+            const unsigned c0 = hist[255 - 4 * lane], c1 = hist[254 - 4 * lane];
+            const unsigned c2 = hist[253 - 4 * lane], c3 = hist[252 - 4 * lane];
+            const unsigned s4 = c0 + c1 + c2 + c3;
+            unsigned incl = s4;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned t = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += t;
+            }
+            const unsigned excl = incl - s4;
+            const unsigned kk = sel[1];
+            if (excl < kk && kk <= incl) {  // exactly one lane: the k-th largest is in its bins
+                unsigned cum = excl;
+                int bsel = 255 - 4 * lane;
+                if (cum + c0 < kk) {
+                    cum += c0; bsel -= 1;
+                    if (cum + c1 < kk) {
+                        cum += c1; bsel -= 1;
+                        if (cum + c2 < kk) { cum += c2; bsel -= 1; }
+                    }
+                }
+                sel[1] = kk - cum;
+                sel[0] = prefix | ((unsigned)bsel << shift);
+            }
+        }
+        __syncthreads();
+    }
+    return sel[0];
+}
+
 template <typename D>
 __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(SampleArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float vals[];  // [V]
-    __shared__ unsigned hist[256];
-    __shared__ float red_f[SMP_THREADS / 64];
+    extern __shared__ __attribute__((aligned(16))) float vals[];  // [V]: only the radix fallback uses it
+    __shared__ unsigned hist[SMP_NB];
+    __shared__ float cand[SMP_CAND];
+    __shared__ float red_f[SMP_THREADS / 64], red_g[SMP_THREADS / 64];
     __shared__ int red_i[SMP_THREADS / 64];
-    __shared__ unsigned sel_prefix, sel_k;
-    __shared__ float sh_f;
+    __shared__ unsigned wtot[SMP_THREADS / 64];
+    __shared__ unsigned sel[2], ncand;
+    __shared__ float sh_f, sh_g, sh_thr;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int b = blockIdx.x, V = a.V, B = a.B;
     const int step = a.state[1];
@@ -56,14 +128,14 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(SampleArgs a) {
     const float tdiv = fmaxf(a.temperature, 1e-5f);
 
     // 0. request everything this thread will ever read from HBM
-    float lc[SMP_NS][8], lu[SMP_NS][8], nz[SMP_NS][8];
+    float l[SMP_NS][8], lu[SMP_NS][8], nz[SMP_NS][8];
     bool own[SMP_NS];
 #pragma unroll
     for (int s = 0; s < SMP_NS; ++s) {
         const int i0 = (s * SMP_THREADS + tid) * 8;
         own[s] = i0 < V;  // V % 8 == 0
         const int ic = own[s] ? i0 : 0;
-        D::ld8(a.logits, (size_t)b * V + ic, lc[s]);
+        D::ld8(a.logits, (size_t)b * V + ic, l[s]);
         if (mix) D::ld8(a.logits, (size_t)(B + b) * V + ic, lu[s]);
         if (!a.greedy) {
             const float4* np = (const float4*)(a.noise + (size_t)step * a.noise_stride + (size_t)b * V + ic);
@@ -72,116 +144,141 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(SampleArgs a) {
             nz[s][4] = n1.x; nz[s][5] = n1.y; nz[s][6] = n1.z; nz[s][7] = n1.w;
         }
     }
+    for (int i = tid; i < SMP_NB; i += SMP_THREADS) hist[i] = 0;
+    if (tid == 0) ncand = 0;
 
-    // 1. CFG mix + temperature -> LDS, row max
-    float lmax = -INFINITY;
+    // 1. CFG mix + temperature (in registers), row max / min
+    float lmax = -INFINITY, lmin = INFINITY;
 #pragma unroll
     for (int s = 0; s < SMP_NS; ++s) {
-        if (own[s]) {
-            float l[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float v = lc[s][e];
-                if (mix) v = lu[s][e] + (v - lu[s][e]) * a.cfg_scale;
-                v = v / tdiv;
-                l[e] = v;
-                lmax = fmaxf(lmax, v);
-            }
-            float4* vp = (float4*)(vals + (s * SMP_THREADS + tid) * 8);
-            vp[0] = make_float4(l[0], l[1], l[2], l[3]);
-            vp[1] = make_float4(l[4], l[5], l[6], l[7]);
+        for (int e = 0; e < 8; ++e) {
+            float v = l[s][e];
+            if (mix) v = lu[s][e] + (v - lu[s][e]) * a.cfg_scale;
+            v = v / tdiv;
+            l[s][e] = v;
+            if (own[s]) { lmax = fmaxf(lmax, v); lmin = fminf(lmin, v); }
         }
     }
     lmax = wave_max(lmax);
-    if (lane == 0) red_f[wv] = lmax;
+    lmin = -wave_max(-lmin);
+    if (lane == 0) { red_f[wv] = lmax; red_g[wv] = lmin; }
     __syncthreads();
     if (tid == 0) {
-        float m = red_f[0];
-        for (int i = 1; i < SMP_THREADS / 64; ++i) m = fmaxf(m, red_f[i]);
-        sh_f = m;
+        float m = red_f[0], n = red_g[0];
+        for (int i = 1; i < SMP_THREADS / 64; ++i) { m = fmaxf(m, red_f[i]); n = fminf(n, red_g[i]); }
+        sh_f = m; sh_g = n;
     }
     __syncthreads();
-    const float rmax = sh_f;
+    const float rmax = sh_f, rmin = sh_g;
 
-    // 2. top-k: key of the k-th largest value (strict '<' removal keeps ties, generate.py:35)
-    uint32_t thr_key = 0;  // keep everything
+    // 2. top-k threshold = k-th largest value (strict '<' removal keeps ties, generate.py:35)
+    float thr = -INFINITY;  // keep everything
     int k = a.top_k;
     if (k > 0) k = k < 1 ? 1 : (k > V ? V : k);
     if (k > 0 && k < V) {
-        if (tid == 0) { sel_prefix = 0; sel_k = (unsigned)k; }
-        for (int pass = 0; pass < 4; ++pass) {
-            const int shift = 24 - 8 * pass;
-            if (tid < 256) hist[tid] = 0;
-            __syncthreads();
-            const unsigned prefix = sel_prefix;
-            const unsigned pmask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
-            for (int i = tid; i < V; i += SMP_THREADS) {
-                const uint32_t key = fkey(vals[i]);
-                bool act = (key & pmask) == prefix;
-                const unsigned bin = (key >> shift) & 0xffu;
-                if (pass == 0) {  // wave-aggregated: few distinct exponent bins
-                    unsigned long long todo = __ballot(act);
-                    while (todo) {
-                        const int leader = __ffsll((long long)todo) - 1;
-                        const unsigned lb = __shfl(bin, leader, 64);
-                        const unsigned long long same = __ballot(act && bin == lb);
-                        if (lane == leader) atomicAdd(&hist[lb], (unsigned)__popcll(same));
-                        todo &= ~same;
-                        if (bin == lb) act = false;
-                    }
-                } else if (act) {
-                    atomicAdd(&hist[bin], 1u);
-                }
-            }
-            __syncthreads();
-            if (wv == 0) {  // one wave scans the 256 bins from the top (4 bins per lane)
-                const unsigned c0 = hist[255 - 4 * lane], c1 = hist[254 - 4 * lane];
-                const unsigned c2 = hist[253 - 4 * lane], c3 = hist[252 - 4 * lane];
-                const unsigned s4 = c0 + c1 + c2 + c3;
-                unsigned incl = s4;
+        const float range = rmax - rmin;
+        bool ok = range > 0.f && range < 3.0e38f;  // finite, non-constant row
+        const float scale = ok ? (float)SMP_NB / range : 0.f;
+        int bins[SMP_NS][8];
+        if (ok) {
 #pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const unsigned t = __shfl_up(incl, o, 64);
-                    if (lane >= o) incl += t;
+            for (int s = 0; s < SMP_NS; ++s)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    int bi = (int)((l[s][e] - rmin) * scale);
+                    bi = bi > SMP_NB - 1 ? SMP_NB - 1 : bi;
+                    bins[s][e] = bi;
+                    if (own[s]) atomicAdd(&hist[bi], 1u);
                 }
-                const unsigned excl = incl - s4;
-                const unsigned kk = sel_k;
-                if (excl < kk && kk <= incl) {  // exactly one lane: the k-th largest is in its bins
-                    unsigned cum = excl;
-                    int bsel = 255 - 4 * lane;
-                    if (cum + c0 < kk) {
-                        cum += c0; bsel -= 1;
-                        if (cum + c1 < kk) {
-                            cum += c1; bsel -= 1;
-                            if (cum + c2 < kk) { cum += c2; bsel -= 1; }
-                        }
+        }
+        __syncthreads();
+        if (ok) {
+            // suffix scan over bins, 4 per thread: above = #values in bins higher than this thread's
+            const unsigned c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
+            const unsigned s4 = c0 + c1 + c2 + c3;
+            unsigned incl = s4;  // inclusive suffix sum within the wave (lanes >= this one)
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned t = __shfl_down(incl, o, 64);
+                if (lane + o < 64) incl += t;
+            }
+            if (lane == 0) wtot[wv] = incl;
+            __syncthreads();
+            unsigned above = incl - s4;
+            for (int w2 = wv + 1; w2 < SMP_THREADS / 64; ++w2) above += wtot[w2];
+            const unsigned kk = (unsigned)k;
+            if (above < kk && kk <= above + s4) {  // exactly one thread
+                unsigned cum = above;
+                int bsel = 4 * tid + 3;
+                if (cum + c3 < kk) {
+                    cum += c3; bsel -= 1;
+                    if (cum + c2 < kk) {
+                        cum += c2; bsel -= 1;
+                        if (cum + c1 < kk) { cum += c1; bsel -= 1; }
                     }
-                    sel_k = kk - cum;
-                    sel_prefix = prefix | ((unsigned)bsel << shift);
                 }
+                sel[0] = (unsigned)bsel;
+                sel[1] = kk - cum;  // rank (1 = largest) inside the critical bin
             }
             __syncthreads();
+            const int bsel = (int)sel[0];
+#pragma unroll
+            for (int s = 0; s < SMP_NS; ++s)
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (own[s] && bins[s][e] == bsel) {
+                        const unsigned slot = atomicAdd(&ncand, 1u);
+                        if (slot < SMP_CAND) cand[slot] = l[s][e];
+                    }
+            __syncthreads();
+            const unsigned nc = ncand;
+            if (nc <= SMP_CAND) {
+                const unsigned need = sel[1];
+                if ((unsigned)tid < nc) {
+                    const float ci = cand[tid];
+                    unsigned gt = 0, ge = 0;
+                    for (unsigned j = 0; j < nc; ++j) {
+                        const float cj = cand[j];
+                        gt += cj > ci;
+                        ge += cj >= ci;
+                    }
+                    if (gt < need && need <= ge) sh_thr = ci;  // equal candidates write the same value
+                }
+                __syncthreads();
+                thr = sh_thr;
+            } else {
+                ok = false;  // block-uniform: nc comes from LDS
+            }
         }
-        thr_key = sel_prefix;
+        if (!ok) {  // exact radix select on an LDS copy of the row
+#pragma unroll
+            for (int s = 0; s < SMP_NS; ++s)
+                if (own[s]) {
+                    float4* vp = (float4*)(vals + (s * SMP_THREADS + tid) * 8);
+                    vp[0] = make_float4(l[s][0], l[s][1], l[s][2], l[s][3]);
+                    vp[1] = make_float4(l[s][4], l[s][5], l[s][6], l[s][7]);
+                }
+            __syncthreads();
+            const uint32_t key = radix_kth_key(vals, V, k, hist, sel);
+            // invert fkey: the threshold value itself
+            const uint32_t u = (key & 0x80000000u) ? (key & 0x7fffffffu) : ~key;
+            thr = __uint_as_float(u);
+        }
     }
 
     // 3. softmax over kept entries (max of kept == row max) and argmax(p / q), on the owned slots
     float ex[SMP_NS][8];
     float lsum = 0.f;
 #pragma unroll
-    for (int s = 0; s < SMP_NS; ++s) {
-        if (own[s]) {
-            const float4* vp = (const float4*)(vals + (s * SMP_THREADS + tid) * 8);
-            const float4 a0 = vp[0], a1 = vp[1];
-            const float l[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    for (int s = 0; s < SMP_NS; ++s)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                ex[s][e] = fkey(l[e]) >= thr_key ? expf(l[e] - rmax) : 0.f;
-                lsum += ex[s][e];
-            }
+        for (int e = 0; e < 8; ++e) {
+            ex[s][e] = (own[s] && l[s][e] >= thr) ? expf(l[s][e] - rmax) : 0.f;
+            lsum += ex[s][e];
         }
-    }
     lsum = wave_sum(lsum);
+    __syncthreads();
     if (lane == 0) red_f[wv] = lsum;
     __syncthreads();
     if (tid == 0) {

@@ -286,6 +286,37 @@ def test_sampler_index_exact(dt, B, V, cfg, interval, step, temp, topk, greedy):
     assert (seq[:, :step] == -1).all() and (seq[:, step + 1:] == -1).all()
 
 
+@pytest.mark.parametrize("kind", ["constant", "plateau", "two_values", "huge_range"])
+def test_sampler_degenerate_rows(kind):
+    """Rows the one-pass histogram cannot resolve (constant rows, thousands of equal values in the critical
+    bin, extreme outliers) take the exact radix fallback: indices must still equal the oracle's."""
+    L, dev = _L(), _dev()
+    B, V, topk = 4, 16384, 2000
+    g = torch.Generator().manual_seed(7)
+    logits = torch.randn(B, V, generator=g)
+    if kind == "constant":
+        logits[:] = 0.25
+    elif kind == "plateau":  # 12000 equal values straddling the k-th largest
+        logits[:, :12000] = 0.5
+    elif kind == "two_values":
+        logits[:] = -1.0
+        logits[:, ::3] = 2.0
+    else:  # one outlier stretches the bins so that everything else falls into one of them
+        logits[:, 5] = 3.0e6
+        logits[:, 9] = -3.0e6
+    noise = torch.empty(B, V).exponential_(1, generator=g)
+    cur = torch.zeros(B, dtype=torch.int32, device=dev)
+    seq = torch.full((B, 4), -1, dtype=torch.int32, device=dev)
+    state = torch.tensor([3, 1], dtype=torch.int32, device=dev)
+    nz_all = torch.zeros(2, B, V, device=dev)
+    nz_all[1] = noise.to(dev)
+    lg_d = logits.to(dev)
+    L.check(L.lib().lgen_sample(L.ptr(lg_d), L.ptr(nz_all), B * V, L.ptr(cur), L.ptr(seq), L.ptr(state), B, V, 4,
+                                0, 1.0, -1, 1.0, topk, 1.0, 0, L.F32, L.stream()), "sample")
+    idx, _ = O.sample(logits, temperature=1.0, top_k=topk, top_p=1.0, sample_logits=True, noise=noise)
+    assert seq[:, 1].cpu().tolist() == idx.view(-1).tolist()
+
+
 # ------------------------------------------------------------------------------------------------
 def _hip_model(case):
     m, sd = build_gpt_holder(case)

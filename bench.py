@@ -8,7 +8,7 @@
 
 One "step" = one pass of the hot path over one batch of 32 images per GPU (synthetic class labels,
 random-init weights of the real architecture with output.weight re-randomised, bf16 GPT + fp32-class
-VQ decoder), inputs resident in HBM.  Consecutive steps are independent batches, so `--lanes` (default 2)
+VQ decoder), inputs resident in HBM.  Consecutive steps are independent batches, so `--lanes` (default: 1..3, chosen from K)
 of them are kept in flight per GPU on separate HIP streams (llamagen_amd/pipeline.py: the decode chain
 is latency-bound, two chains interleave on the chip); all K timed steps start and finish inside the
 timed region.  N > 1 shards independent images over ranks (weak scaling, no collective during
@@ -158,9 +158,10 @@ def cpu_baseline(steps=12):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--lanes", type=int, default=2, help="batches in flight per GPU (llamagen_amd/pipeline.py)")
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--lanes", type=int, default=0, help="batches in flight per GPU (llamagen_amd/pipeline.py); "
+                                                         "0 = pick 1..3 from the step count")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -179,6 +180,11 @@ def main():
     gpt, vq = build_models(dev, seed)
     skw = dict(cfg_scale=CFG, cfg_interval=-1, temperature=1.0, top_k=TOPK, top_p=1.0, sample_logits=True)
     N = LAT * LAT
+    if args.lanes <= 0:
+        # k batches in flight take ~T_k (measured, relative to one batch alone: 1, 1.44, 2.02); a run of K steps on L
+        # lanes costs floor(K/L) * T_L + T_(K mod L): use the cheapest L
+        T = {0: 0.0, 1: 1.0, 2: 1.44, 3: 2.02}
+        args.lanes = min((1, 2, 3), key=lambda l: (args.steps // l) * T[l] + T[args.steps % l])
     pipe = SamplingPipeline(gpt, vq, lanes=args.lanes)
     pipe.prepare(BATCH, N, **skw)  # setup (like loading weights): KV slabs, workspaces, decode graphs per lane
     torch.cuda.synchronize()

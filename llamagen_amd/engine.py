@@ -123,7 +123,7 @@ class DecodeEngine:
         elif mts == 3:
             mts = 4
         self.MTs = mts
-        self.mt = min(mts, 8) if mts % 8 == 0 else mts  # m-tiles per workgroup (1, 2, 4 or 8)
+        self.mt = min(mts, 4)  # m-tiles per workgroup (1, 2 or 4; MTs is 1, 2, 4 or a multiple of 8)
         dev, dt = self.dev, dtype
         z = lambda *s, dtype=dt: torch.zeros(*s, dtype=dtype, device=dev)
         # KV slabs (gpt.py:170-185); hd padded to 64/128 so a key row is a power-of-two lane group

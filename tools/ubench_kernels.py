@@ -63,15 +63,15 @@ def main(name="GPT-L", B=32, img=384):
     report("embed_pack (+ssq)", lambda: [e._embed(e.tok_emb, e.cur_tok) for _ in range(50)], 50)
     e.ssq_parts = d // e.kc
     for kind, tiles_list in {
-        "qkv": [(4, 1, 8), (4, 1, 4), (4, 2, 8), (2, 1, 8), (1, 1, 8)],
-        "wo": [(4, 1, 8), (2, 1, 8), (1, 1, 8)],
-        "w13": [(4, 2, 8), (2, 4, 8), (4, 4, 8)],
-        "w2": [(4, 1, 8), (2, 1, 8), (1, 1, 8)],
+        "qkv": [(1, 4, 8)],
+        "wo": [(1, 1, 8)],
+        "w13": [(2, 4, 8)],
+        "w2": [(1, 1, 16)],
     }.items():
         for tl in tiles_list:
-            for norm in ((True, False) if kind in ("qkv", "w13") else (False,)):
+            for norm, hot in (((True, False), (True, True)) if kind in ("qkv", "w13") else ((False, False), (False, True))):
                 def fn():
-                    for w in e.layers:
+                    for w in ([e.layers[0]] * nl if hot else e.layers):
                         if kind == "qkv":
                             L.check(lib.lgen_gemm_qkv_rope(L.ptr(w["wqkv"]), L.ptr(e.hp), L.ptr(e.qbuf), L.ptr(e.k_cache[0]), L.ptr(e.v_cache[0]),
                                                            L.ptr(e.freqs_cis), L.ptr(e.state), M, mts, d, H, hd, hdp, S8, dt, tl[0], tl[1], tl[2],
@@ -84,7 +84,7 @@ def main(name="GPT-L", B=32, img=384):
                             e.gemm(w["w2"], e.gp, e.hp, M, mts, d, F, L.EPI_RES, tl, ssq_out=e.ssq)
                 nb = {"qkv": 3 * d * d, "wo": d * d, "w13": 2 * F * d, "w2": F * d}[kind] * 2
                 try:
-                    report(f"{kind} {tl} norm={norm}", fn, nl, nb)
+                    report(f"{kind} {tl} norm={norm} weights {'MALL-hot (same layer)' if hot else 'cold (24 layers)'}", fn, nl, nb)
                 except Exception as ex:
                     print(kind, tl, norm, "->", ex)
     for tl in [(4, 2, 8), (4, 4, 8), (4, 4, 4)]:

@@ -22,7 +22,10 @@ import os
 import sys
 import time
 
-import torch
+# HIP maps streams onto this many hardware queues (default 4); lanes that share a queue serialise
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -229,7 +232,11 @@ def main():
             assert nl == launches, (nl, launches)
             ach = nbytes / sec / 1e9
             res["roofline"] = {"bound": "hbm", "kernel": "attn_decode_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                               "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                               # PMC pass (profiles/r01_attn_decode_pmc.csv: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+                               # separate runs, FETCH x2 gfx950 correction): fetched = 1.002 x algorithmic KV bytes,
+                               # written = the 128 KiB output tile -> per average launch:
+                               "traffic": int(1.002 * nbytes / launches + 131072),
                                "avg_launch_us": round(sec / launches * 1e6, 2),
                                "algorithmic_bytes_per_launch": int(nbytes / launches),
                                "launch_us_by_position": per_pos}

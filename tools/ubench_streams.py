@@ -20,7 +20,6 @@ def build(name, B, N, dev, stream):
         generate(m, c, N, **kw)
     torch.cuda.synchronize()
     e = m._engine
-    e.fuse_norm = os.environ.get("FUSE", "0") == "1"
     e.k_cache.normal_(0, 1)
     e.v_cache.normal_(0, 1)
     e.noise = torch.empty(N, B, 16384, device=dev).exponential_(1.0)
@@ -45,28 +44,36 @@ def main(name="GPT-L", B=32, img=384):
     dev = torch.device("cuda:0")
     N = (img // 16) ** 2
     from llamagen_amd import _lib as L
-    L.lib().lgen_set_attn_variant(int(os.environ.get("ATTV", "1")))
+    tilesets = {
+        "default": {},
+        "half-WG": {"qkv": (2, 4, 8), "w13": (4, 4, 8), "wo": (2, 1, 8), "w2": (2, 1, 16)},
+        "quarter-WG": {"qkv": (4, 4, 8), "w13": (4, 4, 8), "wo": (4, 1, 8), "w2": (4, 1, 8)},
+    }
     for G in (1, 2, 3):
         streams = [torch.cuda.Stream() for _ in range(G)]
         engs = [build(name, B, N, dev, s) for s in streams]
-        for m, e in engs:
-            e.tile_override = {"w2": (1, 1, 8), "wo": (1, 1, 8)}
-        for pos in (8, N // 2, N - 40):
-            gs = [capture(e, B, pos, s) for (m, e), s in zip(engs, streams)]
-            best = 1e9
-            for _ in range(3):
-                for (g, st), (m, e) in zip(gs, engs):
-                    e.state.copy_(st)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(20):
-                    for (g, st), s in zip(gs, streams):
-                        with torch.cuda.stream(s):
-                            g.replay()
-                torch.cuda.synchronize()
-                best = min(best, (time.perf_counter() - t0) / 20 * 1e6)
-            print(f"{G} concurrent batches x {B} images, pos {pos}: {best:8.1f} us per step of all -> {best / G:8.1f} us per batch-step", flush=True)
-        del engs, gs
+        for tname, tiles in tilesets.items():
+            for m, e in engs:
+                e.tile_override = dict(tiles)
+            res = []
+            for pos in (8, N // 2):
+                gs = [capture(e, B, pos, s) for (m, e), s in zip(engs, streams)]
+                best = 1e9
+                for _ in range(3):
+                    for (g, st), (m, e) in zip(gs, engs):
+                        e.state.copy_(st)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(20):
+                        for (g, st), s in zip(gs, streams):
+                            with torch.cuda.stream(s):
+                                g.replay()
+                    torch.cuda.synchronize()
+                    best = min(best, (time.perf_counter() - t0) / 20 * 1e6)
+                res.append(f"pos {pos}: {best / G:7.1f} us/batch-step")
+                del gs
+            print(f"{G} concurrent batches, tiles {tname:10s}: " + "   ".join(res), flush=True)
+        del engs
 
 
 if __name__ == "__main__":

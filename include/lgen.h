@@ -139,6 +139,11 @@ int lgen_conv_igemm(const void* a_hi, const void* a_lo, const void* w_hi, const 
                     const float* res, float* out, int B, int H, int W, int Cin, int Cout, int Npad, int ksize,
                     int upsample, int out_nchw, long long w_bstride, float alpha, void* stream);
 
+/* One-shot hint (per host thread): the next lgen_gemm / lgen_gemm_qkv_rope / lgen_attn_decode launch also
+ * issues fire-and-forget reads of [next_weights, +bytes) -- the weight matrix of the kernel that follows it in
+ * the decode chain -- so that the successor starts on a warm memory-side cache.  NULL clears it. */
+int lgen_prefetch_hint(const void* next_weights, long long bytes);
+
 /* ---- tuning knobs (process-wide kernel variant selection; defaults are the measured-best ones) ---- */
 int lgen_set_attn_variant(int v);  /* 1 (default): 2 K/V loads per buffer, all B2*H workgroups resident; 0: 4 */
 int lgen_set_igemm_variant(int v); /* 0 (default): 128x128 tile, 1 staging set; 1: 2 sets; 2: 128x64 tiles, 2 sets */

@@ -21,7 +21,30 @@ struct GemmArgs {
     int d, hd, hdp, H, S8;
     int parts;
     float eps, inv_k;
+    const char* pf;      // weights of the NEXT kernel of the chain (nullable): pulled towards the memory-side cache
+    long long pf_bytes;
 };
+
+// Fire-and-forget reads of the next kernel's weight matrix, one dword per 64-byte line, issued BEFORE this
+// wave's own operand loads.  Each kernel of the decode chain is latency-bound and starts with a cold weight
+// stream (~1 us of its ~5 us); the chain's successor finds its weights in the memory-side cache instead.
+// Only 4 bytes per line travel to the CU, and loads retire in order, so by the time the wave's own operands
+// (requested later) have arrived these have too: nothing ever waits specifically for them.  Inline asm
+// because hipcc must neither eliminate the loads nor reuse their destination register early: the returned
+// token has to be passed to prefetch_retire() AFTER the wave has consumed its own loads.
+LGEN_DEV unsigned prefetch_lines(const char* base, long long bytes, int part, int nparts, int lane) {
+    unsigned junk = 0;
+    if (!base) return junk;
+    const long long per = ((bytes / nparts + 4095) / 4096) * 4096;  // bytes per participating wave
+    const long long lo = (long long)part * per;
+    for (long long off = lo + lane * 64; off < lo + per && off < bytes; off += 4096) {
+        const char* p = base + off;
+        asm volatile("global_load_dword %0, %1, off" : "+v"(junk) : "v"(p));
+    }
+    return junk;
+}
+// vmcnt(0): free when the wave has consumed its own (younger) loads; required for waves that had none
+LGEN_DEV void prefetch_retire(unsigned token) { asm volatile("s_waitcnt vmcnt(0)" ::"v"(token) : "memory"); }
 
 LGEN_DEV float silu_f(float x) { return x / (1.0f + expf(-x)); }
 LGEN_DEV float gelu_tanh_f(float x) {
@@ -119,3 +142,4 @@ template <int EPI> constexpr bool epi_has_aux() { return EPI == EPI_RES || EPI =
 // gemm_normpre.hip: RMSNorm-fused GEMM that normalises while its weights are in flight (small K per wave);
 // returns LGEN_ERR_UNSUPPORTED when the shape is outside its envelope (caller falls back).
 int lgen_gemm_normpre_try(const GemmArgs& a, int epi, int dtype, int mt, int nt, int kw, hipStream_t st);
+void lgen_take_prefetch_hint(const char** p, long long* n);  // gemm_skinny.hip

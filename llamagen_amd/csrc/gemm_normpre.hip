@@ -29,6 +29,8 @@ __global__ __launch_bounds__(512) void gemm_normpre_kernel(GemmArgs a) {
     int pos = 0;
     if constexpr (EPI == EPI_QKV) pos = *a.pos_ptr;
 
+    const unsigned pf_token = prefetch_lines(a.pf, a.pf_bytes, (blockIdx.y * gridDim.x + blockIdx.x) * KW + w,
+                                             gridDim.x * gridDim.y * KW, lane);
     // 1. activations, norm weights, row statistics
     uint4 B[CPW][MT], WN[CPW];
     const uint4* xbase = a.xp + (size_t)mt0 * 64 + lane;
@@ -94,6 +96,8 @@ __global__ __launch_bounds__(512) void gemm_normpre_kernel(GemmArgs a) {
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < NT; ++j) acc[j][i] = D::mma(A[c][j], B[c][i], acc[j][i]);
+
+    prefetch_retire(pf_token);
 
     if (KW == 1) {
 #pragma unroll

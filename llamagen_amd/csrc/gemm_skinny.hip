@@ -64,6 +64,8 @@ __global__ __launch_bounds__((gemm_max_threads<MT, NT, NORM, EPI>())) void gemm_
     const size_t wstride = (size_t)a.KCH * 64;
     const size_t xstride = (size_t)a.MTs * 64;
 
+    const unsigned pf_token = prefetch_lines(a.pf, a.pf_bytes, (blockIdx.y * gridDim.x + blockIdx.x) * KW + w,
+                                             gridDim.x * gridDim.y * KW, lane);
     uint4 A[DEPTH][NT], B[DEPTH][MT], WN[DEPTH];
 #define LGEN_LOAD(s, kk)                                                                                  \
     {                                                                                                     \
@@ -145,6 +147,8 @@ __global__ __launch_bounds__((gemm_max_threads<MT, NT, NORM, EPI>())) void gemm_
         if (k + s < k1) LGEN_MMA(s);
 #undef LGEN_LOAD
 #undef LGEN_MMA
+
+    prefetch_retire(pf_token);
 
     if (KW == 1) {
 #pragma unroll
@@ -256,6 +260,20 @@ static int dispatch_norm(const GemmArgs& a, int dtype, int mt, int nt, int kw, h
     return dispatch_dt<EPI, false>(a, dtype, mt, nt, kw, st);
 }
 
+// One-shot host-side hint consumed by the next lgen_gemm / lgen_gemm_qkv_rope / lgen_attn_decode launch of
+// this thread (it is baked into that launch's kernel arguments, so a captured graph keeps it).
+thread_local const char* g_pf_ptr = nullptr;
+thread_local long long g_pf_bytes = 0;
+extern "C" int lgen_prefetch_hint(const void* next_weights, long long bytes) {
+    g_pf_ptr = (const char*)next_weights;
+    g_pf_bytes = next_weights ? bytes : 0;
+    return 0;
+}
+void lgen_take_prefetch_hint(const char** p, long long* n) {
+    *p = g_pf_ptr; *n = g_pf_bytes;
+    g_pf_ptr = nullptr; g_pf_bytes = 0;
+}
+
 extern "C" int lgen_gemm_max_kw(int epilogue_kind, int fused_norm, int mt, int nt) {
     switch (epilogue_kind) {
         case LGEN_EPI_ROWS: return fused_norm ? max_kw_of<EPI_ROWS, true>(mt, nt) : max_kw_of<EPI_ROWS, false>(mt, nt);
@@ -278,6 +296,7 @@ extern "C" int lgen_gemm(const void* wp, const void* xp, void* out, int M, int M
     a.N = N; a.KCH = K / kcsz; a.MTs = MTs; a.M = M;
     a.nw = (const uint4*)norm_w; a.ssq_in = ssq_in; a.parts = ssq_parts; a.eps = eps; a.inv_k = 1.0f / (float)K;
     a.ssq_out = ssq_out;
+    lgen_take_prefetch_hint(&a.pf, &a.pf_bytes);
     hipStream_t st = (hipStream_t)stream;
     if (ssq_out && epilogue_kind != LGEN_EPI_RES) return LGEN_ERR_BAD_ARG;
     switch (epilogue_kind) {
@@ -302,5 +321,6 @@ extern "C" int lgen_gemm_qkv_rope(const void* wp, const void* xp, void* q_out, v
     a.N = 3 * d; a.KCH = d / kcsz; a.MTs = MTs; a.M = M;
     a.d = d; a.hd = hd; a.hdp = hdp; a.H = n_head; a.S8 = S8;
     a.nw = (const uint4*)norm_w; a.ssq_in = ssq_in; a.parts = ssq_parts; a.eps = eps; a.inv_k = 1.0f / (float)d;
+    lgen_take_prefetch_hint(&a.pf, &a.pf_bytes);
     return dispatch_norm<EPI_QKV>(a, dtype, mt, nt, kw, (hipStream_t)stream);
 }

@@ -4,8 +4,7 @@
 //   lgen_rmsnorm      RMSNorm on the packed layout (gpt.py:137-148), two bf16 rounding points
 //   lgen_attn_decode  KV-cached single-query attention over kv_len = pos+1 keys only
 //                     (gpt.py:229-236 repeat_interleave + math-SDPA with causal_mask[:, pos])
-#include "lgen_common.h"
-#include "../../include/lgen.h"
+#include "gemm_epilogue.h"
 
 // ---------------------------------------------------------------------------------------------
 // embedding gather: hp[k-chunk][mt][lane] <- table[idx[m]][k..]   (16 B per thread), plus
@@ -204,6 +203,8 @@ struct AttnArgs {
     const unsigned char* mask;  // null (pure causal) or causal_mask [B2][S8][S8] bytes: row `pos` is read
     int H, hd, hdp, S8, MTs;
     float sf;            // sqrt(1/sqrt(hd))
+    const char* pf;      // next kernel's weights (wo), see prefetch_lines in gemm_epilogue.h
+    long long pf_bytes;
 };
 
 #define ATT_NW 4
@@ -224,6 +225,7 @@ __global__ __launch_bounds__(64 * ATT_NW, (ATT_CH <= 2 ? 4 : 2)) void attn_decod
     const uint4* vp = (const uint4*)a.vc + rowbase * lpr + part;
     const int smax = a.S8 - 1;
 
+    const unsigned pf_token = prefetch_lines(a.pf, a.pf_bytes, blockIdx.x * ATT_NW + wv, gridDim.x * ATT_NW, lane);
     uint4 k0[ATT_CH], v0[ATT_CH], k1[ATT_CH], v1[ATT_CH];
 #define ATT_LOAD(KB, VB, g)                                                 \
     {                                                                       \
@@ -292,6 +294,7 @@ __global__ __launch_bounds__(64 * ATT_NW, (ATT_CH <= 2 ? 4 : 2)) void attn_decod
     }
 #undef ATT_LOAD
 #undef ATT_COMPUTE
+    prefetch_retire(pf_token);
     // combine the KPL key groups of this wave (lanes with equal `part`)
 #pragma unroll
     for (int o = LPK; o < 64; o <<= 1) {
@@ -330,7 +333,8 @@ extern "C" int lgen_set_attn_variant(int v) { g_attn_variant = v; return 0; }
 extern "C" int lgen_attn_decode(const void* q, const void* k_cache, const void* v_cache, void* out_packed,
                                 const int* pos_ptr, const unsigned char* mask, int B2, int MTs, int n_head,
                                 int hd, int hdp, int S8, int dtype, void* stream) {
-    AttnArgs a{q, k_cache, v_cache, out_packed, pos_ptr, mask, n_head, hd, hdp, S8, MTs, 0.f};
+    AttnArgs a{q, k_cache, v_cache, out_packed, pos_ptr, mask, n_head, hd, hdp, S8, MTs, 0.f, nullptr, 0};
+    lgen_take_prefetch_hint(&a.pf, &a.pf_bytes);
     a.sf = sqrtf(1.0f / sqrtf((float)hd));
     hipStream_t st = (hipStream_t)stream;
     const int epl = dtype == LGEN_BF16 ? 8 : 4;

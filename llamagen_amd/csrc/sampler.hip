@@ -120,6 +120,9 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(SampleArgs a) {
     __shared__ unsigned wtot[SMP_THREADS / 64];
     __shared__ unsigned sel[2], ncand;
     __shared__ float sh_f, sh_g, sh_thr;
+    __shared__ unsigned long long hm[SMP_NB];       // top-p: probability mass per value bin, 2^-40 fixed point
+    __shared__ unsigned long long wtot64[SMP_THREADS / 64], sh_gab;
+    __shared__ unsigned sh_key;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int b = blockIdx.x, V = a.V, B = a.B;
     const int step = a.state[1];
@@ -287,7 +290,100 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(SampleArgs a) {
         sh_f = s;
     }
     __syncthreads();
-    const float tot = sh_f;
+    float tot = sh_f;
+
+    // 3b. nucleus (top-p) filter on the top-k survivors (generate.py:38-53): an entry stays iff the probability
+    // mass of the strictly larger entries is <= top_p (the reference's shifted `cumsum > top_p` removal; entries
+    // of equal value share their fate here, where the reference's unstable sort picks arbitrarily).  Masses are
+    // 2^-40 fixed point, so every sum is order-independent: value-bin mass histogram -> critical bin by suffix
+    // scan -> exact mass ranking inside that bin.
+    if (a.top_p < 1.0f) {
+        const float range = rmax - rmin;
+        if (range > 0.f && range < 3.0e38f) {  // a constant row keeps everything (no strictly larger entry)
+            const float scale = (float)SMP_NB / range;
+            const unsigned long long P = (unsigned long long)((double)a.top_p * 1099511627776.0);
+            auto mass = [&](float e) { return (unsigned long long)((double)(e / tot) * 1099511627776.0); };
+            for (int i = tid; i < SMP_NB; i += SMP_THREADS) hm[i] = 0ull;
+            if (tid == 0) { ncand = 0; sh_key = 0xffffffffu; sel[0] = 0xffffffffu; }
+            __syncthreads();
+            int pb[SMP_NS][8];
+#pragma unroll
+            for (int s = 0; s < SMP_NS; ++s)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    int bi = (int)((l[s][e] - rmin) * scale);
+                    bi = bi > SMP_NB - 1 ? SMP_NB - 1 : bi;
+                    pb[s][e] = bi;
+                    if (ex[s][e] > 0.f) atomicAdd(&hm[bi], mass(ex[s][e]));
+                }
+            __syncthreads();
+            const unsigned long long m0 = hm[4 * tid], m1 = hm[4 * tid + 1], m2 = hm[4 * tid + 2], m3 = hm[4 * tid + 3];
+            const unsigned long long s4 = m0 + m1 + m2 + m3;
+            unsigned long long incl = s4;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned long long t = __shfl_down(incl, o, 64);
+                if (lane + o < 64) incl += t;
+            }
+            if (lane == 0) wtot64[wv] = incl;
+            __syncthreads();
+            unsigned long long above = incl - s4;
+            for (int w2 = wv + 1; w2 < SMP_THREADS / 64; ++w2) above += wtot64[w2];
+            {   // critical bin b: mass above b <= P < mass above b + mass of b (walk this thread's bins from the top)
+                unsigned long long g = above;
+                const unsigned long long mm[4] = {m0, m1, m2, m3};
+#pragma unroll
+                for (int q = 3; q >= 0; --q) {
+                    if (g <= P && P < g + mm[q]) { sel[0] = (unsigned)(4 * tid + q); sh_gab = g; }
+                    g += mm[q];
+                }
+            }
+            __syncthreads();
+            const unsigned bstar = sel[0];
+            if (bstar != 0xffffffffu) {  // else: total mass <= top_p (rounding), nothing to remove
+                float* cv = vals;         // candidate values of the critical bin (capacity V)
+#pragma unroll
+                for (int s = 0; s < SMP_NS; ++s)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (ex[s][e] > 0.f && (unsigned)pb[s][e] == bstar) cv[atomicAdd(&ncand, 1u)] = l[s][e];
+                __syncthreads();
+                const unsigned nc = ncand;
+                const unsigned long long gab = sh_gab;
+                for (unsigned i = tid; i < nc; i += SMP_THREADS) {
+                    const float ci = cv[i];
+                    unsigned long long g = gab;
+                    for (unsigned j = 0; j < nc; ++j) {
+                        const float cj = cv[j];
+                        if (cj > ci) g += mass(expf(cj - rmax));
+                    }
+                    if (g <= P) atomicMin(&sh_key, fkey(ci));
+                }
+                __syncthreads();
+                const uint32_t key = sh_key;
+                const float thr_p = __uint_as_float((key & 0x80000000u) ? (key & 0x7fffffffu) : ~key);
+                // re-normalise over the nucleus
+                lsum = 0.f;
+#pragma unroll
+                for (int s = 0; s < SMP_NS; ++s)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        if (!(l[s][e] >= thr_p)) ex[s][e] = 0.f;
+                        lsum += ex[s][e];
+                    }
+                lsum = wave_sum(lsum);
+                if (lane == 0) red_f[wv] = lsum;
+                __syncthreads();
+                if (tid == 0) {
+                    float sacc = 0.f;
+                    for (int i = 0; i < SMP_THREADS / 64; ++i) sacc += red_f[i];
+                    sh_f = sacc;
+                }
+                __syncthreads();
+                tot = sh_f;
+            }
+        }
+    }
 
     float best = -1.f;
     int bidx = 0x7fffffff;
@@ -333,12 +429,11 @@ extern "C" int lgen_sample(const void* logits, const float* noise, long long noi
                            int cfg_interval, float temperature, int top_k, float top_p, int greedy, int dtype,
                            void* stream) {
     if (V > SMP_MAXV || V < 8 || (V & 7) || B < 1) return LGEN_ERR_BAD_ARG;
-    if (top_p < 1.0f) return LGEN_ERR_UNSUPPORTED;
     if (!greedy && !noise) return LGEN_ERR_BAD_ARG;
     SampleArgs a{logits, noise, noise_step_stride, cur_tok, seq, state, B, V, seq_stride, use_cfg, cfg_scale,
                  temperature, top_p, cfg_interval, top_k, greedy};
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds = (size_t)V * sizeof(float);
+    const size_t lds = (size_t)SMP_MAXV * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {  // row (64 KiB) + small statics exceeds the default 64 KiB LDS cap
         hipError_t e1 = hipFuncSetAttribute((const void*)sample_kernel<BF16>, hipFuncAttributeMaxDynamicSharedMemorySize,

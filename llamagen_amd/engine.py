@@ -157,6 +157,10 @@ class DecodeEngine:
         auto = dtype == torch.bfloat16 and kch % 8 == 0 and 3 <= kch // 8 <= 6
         env = os.environ.get("LGEN_FUSED_NORM")
         self.fuse_norm = auto if env is None else env == "1"
+        # lgen_prefetch_hint: every kernel of the chain also touches its successor's weights (one dword per line).
+        # Measured NEGATIVE on MI355X (+106 us per decode step: the extra line requests sit in front of the
+        # kernel's own operand loads), so it is off; LGEN_PREFETCH=1 re-enables it for experiments.
+        self.prefetch = os.environ.get("LGEN_PREFETCH", "0") == "1"
         self.tile_override = {}      # kind ("qkv" | "wo" | "w13" | "w2" | "head") -> (mt, nt, kw)
         self._pack(model)
 
@@ -245,6 +249,12 @@ class DecodeEngine:
                                self._tiles("w2", d, F), self._tiles("head", self.V, d))
         pm = self.causal_mask if self.use_mask else None
         ssq = self.ssq if fuse else None
+
+        def hint(t):
+            if self.prefetch:
+                lib.lgen_prefetch_hint(L.ptr(t), t.numel() * t.element_size())
+
+        nlayers = len(self.layers)
         for i, w in enumerate(self.layers):
             if fuse:
                 x_in, nw = self.hp, w["an"]
@@ -258,11 +268,13 @@ class DecodeEngine:
             if self._prof is not None:  # bench.py roofline leg: HIP events on the launch stream
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
+            hint(w["wo"])
             L.check(lib.lgen_attn_decode(L.ptr(self.qbuf), L.ptr(self.k_cache[i]), L.ptr(self.v_cache[i]), L.ptr(self.ap),
                                          pos_ptr, L.ptr(pm), M, mts, H, hd, hdp, S8, dt, st), "attn_decode")
             if self._prof is not None:
                 e1.record()
                 self._prof["events"].append((e0, e1))
+            hint(w["w13"])
             self.gemm(w["wo"], self.ap, self.hp, M, mts, d, d, L.EPI_RES, to, ssq_out=ssq)
             self.ssq_parts = d // 16
             if fuse:
@@ -270,7 +282,9 @@ class DecodeEngine:
             else:
                 L.check(lib.lgen_rmsnorm(L.ptr(self.hp), L.ptr(w["fn"]), L.ptr(self.xnp), mts, d, self.eps, dt, st), "rmsnorm")
                 x_in, nw = self.xnp, None
+            hint(w["w2"])
             self.gemm(w["w13"], x_in, self.gp, M, mts, 2 * F, d, L.EPI_SWIGLU, t13, norm_w=nw)
+            hint(self.layers[i + 1]["wqkv"] if i + 1 < nlayers else self.out_w)
             self.gemm(w["w2"], self.gp, self.hp, M, mts, d, F, L.EPI_RES, t2, ssq_out=ssq)
         if want_logits:
             if fuse:
@@ -278,6 +292,7 @@ class DecodeEngine:
             else:
                 L.check(lib.lgen_rmsnorm(L.ptr(self.hp), L.ptr(self.norm_w), L.ptr(self.xnp), mts, d, self.eps, dt, st), "rmsnorm")
                 x_in, nw = self.xnp, None
+            hint(self.layers[0]["wqkv"])  # the next decode step starts there
             self.gemm(self.out_w, x_in, self.logits, M, mts, self.V, d, L.EPI_ROWS, th, norm_w=nw)
 
     def _embed(self, table, idx, advance: bool = False):

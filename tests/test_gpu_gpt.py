@@ -251,12 +251,14 @@ def test_qkv_rope_append_and_attention(dt, B2, H, hd, grid, pos):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("B,V,cfg,interval,step,temp,topk,greedy", [
-    (3, 1024, 4.0, -1, 0, 1.0, 100, 0), (32, 16384, 4.0, -1, 5, 1.0, 2000, 0), (5, 2048, 1.0, -1, 3, 0.8, 0, 0),
-    (4, 1024, 3.0, 2, 4, 1.0, 50, 0), (4, 1024, 3.0, 2, 3, 1.0, 50, 0), (2, 16384, 1.5, -1, 1, 1.0, 1, 0),
-    (3, 1024, 4.0, -1, 2, 1.0, 100, 1), (2, 1024, 2.0, -1, 2, 1.0, 5000, 0),
+@pytest.mark.parametrize("B,V,cfg,interval,step,temp,topk,greedy,topp", [
+    (3, 1024, 4.0, -1, 0, 1.0, 100, 0, 1.0), (32, 16384, 4.0, -1, 5, 1.0, 2000, 0, 1.0), (5, 2048, 1.0, -1, 3, 0.8, 0, 0, 1.0),
+    (4, 1024, 3.0, 2, 4, 1.0, 50, 0, 1.0), (4, 1024, 3.0, 2, 3, 1.0, 50, 0, 1.0), (2, 16384, 1.5, -1, 1, 1.0, 1, 0, 1.0),
+    (3, 1024, 4.0, -1, 2, 1.0, 100, 1, 1.0), (2, 1024, 2.0, -1, 2, 1.0, 5000, 0, 1.0),
+    (8, 16384, 4.0, -1, 2, 1.0, 2000, 0, 0.9), (6, 1024, 2.0, -1, 1, 1.0, 0, 0, 0.8), (4, 2048, 1.0, -1, 0, 0.7, 300, 0, 0.5),
+    (4, 16384, 3.0, -1, 3, 1.0, 0, 0, 0.05), (3, 1024, 2.0, -1, 2, 1.0, 0, 1, 0.9),
 ])
-def test_sampler_index_exact(dt, B, V, cfg, interval, step, temp, topk, greedy):
+def test_sampler_index_exact(dt, B, V, cfg, interval, step, temp, topk, greedy, topp):
     L, dev = _L(), _dev()
     code = L.BF16 if dt == torch.bfloat16 else L.F32
     use_cfg = cfg > 1.0
@@ -274,10 +276,10 @@ def test_sampler_index_exact(dt, B, V, cfg, interval, step, temp, topk, greedy):
     nz_all = torch.zeros(step + 1, B, V, device=dev)
     nz_all[step] = nz_d
     L.check(L.lib().lgen_sample(L.ptr(lg_d), L.ptr(nz_all), B * V, L.ptr(cur), L.ptr(seq), L.ptr(state), B, V, 16,
-                                1 if use_cfg else 0, cfg, interval, temp, topk, 1.0, greedy, code, L.stream()), "sample")
+                                1 if use_cfg else 0, cfg, interval, temp, topk, topp, greedy, code, L.stream()), "sample")
     flag = not (step > 0 and interval > -1 and (step - 1) > interval)
     mixed = O.cfg_mix(logits.float(), cfg, flag)
-    idx, _ = O.sample(mixed, temperature=temp, top_k=topk, top_p=1.0, sample_logits=not greedy, noise=noise)
+    idx, _ = O.sample(mixed, temperature=temp, top_k=topk, top_p=topp, sample_logits=not greedy, noise=noise)
     assert seq[:, step].cpu().tolist() == idx.view(-1).tolist()
     assert cur[:B].cpu().tolist() == idx.view(-1).tolist()
     if use_cfg:
@@ -329,7 +331,7 @@ def _noise_seq(case):
     return torch.stack([fn((case["batch"], V)) for _ in range(case["n_new"])])
 
 
-HIP_FP32 = [k for k, c in GPT_CASES.items() if c["dtype"] == "fp32" and c["top_p"] >= 1.0]
+HIP_FP32 = [k for k, c in GPT_CASES.items() if c["dtype"] == "fp32"]
 
 
 @pytest.mark.parametrize("name", HIP_FP32)

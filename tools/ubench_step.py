@@ -70,18 +70,13 @@ def main(name="GPT-L", B=32, img=384, what="all"):
     print("default tiles:", {k: eng._tiles(k, *nk) for k, nk in dict(qkv=(3 * d, d), wo=(d, d), w13=(2 * F, d), w2=(d, F), head=(V, d)).items()})
     # interleaved A/B (run-to-run drift on this box is several %): every config is measured in every round
     configs = {
-        "unfused": dict(fuse=False, tiles={}),
-        "fused default": dict(fuse=True, tiles={}),
-        "fused head(2,4,8)": dict(fuse=True, tiles={"head": (2, 4, 8)}),
-        "fused head(4,4,8)": dict(fuse=True, tiles={"head": (4, 4, 8)}),
-        "fused qkv(2,4,8)": dict(fuse=True, tiles={"qkv": (2, 4, 8)}),
-        "fused qkv(1,4,8)": dict(fuse=True, tiles={"qkv": (1, 4, 8)}),
-        "fused w13(1,4,8)": dict(fuse=True, tiles={"w13": (1, 4, 8)}),
-        "fused wo(2,1,8) w2(2,1,16)": dict(fuse=True, tiles={"wo": (2, 1, 8), "w2": (2, 1, 16)}),
+        "prefetch off": dict(fuse=True, tiles={}, pf=False),
+        "prefetch on": dict(fuse=True, tiles={}, pf=True),
     }
-    for rnd in range(2):
+    for rnd in range(3):
         for tag, c in configs.items():
             eng.fuse_norm = c["fuse"]
+            eng.prefetch = c.get("pf", True)
             eng.tile_override = dict(c["tiles"])
             try:
                 row(f"r{rnd} {tag}")

@@ -131,8 +131,9 @@ int lgen_split_t(const float* x, void* hi, void* lo, int B, int R, int C, int ld
 int lgen_softmax_split(const float* scores, void* hi, void* lo, int rows, int n, int ldo, void* stream);
 
 /* nn.Conv2d 3x3 (pad 1) / 1x1, stride 1 (vq_model.py:288-291,321-324) as implicit GEMM on MFMA with
- * hi/lo-split bf16 operands (3 passes, fp32 accumulate); optional nearest-2x upsample of the input
- * (Upsample, vq_model.py:374-378: a_* is then [B][H/2][W/2][Cin]), bias, residual add (NHWC like out),
+ * hi/lo-split bf16 operands (3 passes, fp32 accumulate); `upsample` = 1: nearest-2x upsample of the input
+ * (Upsample, vq_model.py:374-378: a_* is then [B][H/2][W/2][Cin]); `upsample` = 2: stride-2 Downsample conv
+ * (vq_model.py:389-393: a_* is [B][2H][2W][Cin], zero pad right/bottom); bias, residual add (NHWC like out),
  * NCHW output, scale alpha.  With ksize 1 and w_bstride != 0 it is a batched NT GEMM (torch.bmm of
  * AttnBlock, vq_model.py:337,346).  w_* planes: [taps][Npad][Cin] bf16. */
 int lgen_conv_igemm(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo, const float* bias,

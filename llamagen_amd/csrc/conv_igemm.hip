@@ -31,6 +31,7 @@ struct IgemmArgs {
     const float* res;    // like out (NHWC) or null
     float* out;
     int H, W, Cin, Cout, Npad, ks, ups, out_nchw;
+    int stride;  // 1, or 2 = Downsample (vq_model.py:389-393): input (2H) x (2W), zero pad right/bottom only
     long long a_bstride, w_bstride, o_bstride;
     float alpha;
 };
@@ -51,7 +52,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
     const int b = blockIdx.z;
     const int p0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int HW = a.H * a.W;
-    const int Hs = a.H >> a.ups, Ws = a.W >> a.ups;
+    const int Hs = a.stride == 2 ? a.H * 2 : (a.H >> a.ups), Ws = a.stride == 2 ? a.W * 2 : (a.W >> a.ups);
+    const int Hin = a.stride == 2 ? Hs : a.H, Win = a.stride == 2 ? Ws : a.W;  // bounds of the (virtual) conv input
     const uint16_t* ahi = a.a_hi + (size_t)b * a.a_bstride;
     const uint16_t* alo = a.a_lo + (size_t)b * a.a_bstride;
     const uint16_t* whi = a.w_hi + (size_t)b * a.w_bstride;
@@ -71,7 +73,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
     const int kchunks = a.Cin >> 5;
     const int taps = a.ks * a.ks;
     const int nsteps = taps * kchunks;
-    const int pad = a.ks >> 1;
+    const int pad = a.stride == 2 ? 0 : (a.ks >> 1);
 
     // Two register staging sets: the loads of step s+2 are issued while step s computes and are written
     // to LDS one iteration later, so every global load has two compute phases to land.  All loads are
@@ -87,8 +89,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
         const int dy = tap / a.ks - pad, dx = tap % a.ks - pad;                                         \
         _Pragma("unroll") for (int i = 0; i < A_IT; ++i) {                                              \
             const int idx = t + i * 256;                                                                \
-            int sy = apy[i] + dy, sx = apx[i] + dx;                                                     \
-            P##ok[i] = apv[i] && sy >= 0 && sy < a.H && sx >= 0 && sx < a.W;                            \
+            int sy = apy[i] * a.stride + dy, sx = apx[i] * a.stride + dx;                               \
+            P##ok[i] = apv[i] && sy >= 0 && sy < Hin && sx >= 0 && sx < Win;                            \
             sy = P##ok[i] ? sy >> a.ups : 0;                                                            \
             sx = P##ok[i] ? sx >> a.ups : 0;                                                            \
             const size_t off = (((size_t)sy * Ws + sx) * a.Cin + kc * 32 + (idx & 3) * 8);              \
@@ -240,12 +242,17 @@ extern "C" int lgen_set_igemm_variant(int v) { g_igemm_variant = v; return 0; }
 extern "C" int lgen_conv_igemm(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo, const float* bias,
                                const float* res, float* out, int B, int H, int W, int Cin, int Cout, int Npad, int ksize,
                                int upsample, int out_nchw, long long w_bstride, float alpha, void* stream) {
-    if (Cin % 32 || (ksize != 1 && ksize != 3) || Npad % 16 || Npad < Cout || (upsample && ((H | W) & 1)))
+    const int stride = upsample == 2 ? 2 : 1;  // upsample: 0 none, 1 nearest-2x input, 2 stride-2 Downsample conv
+    if (stride == 2) upsample = 0;
+    if (Cin % 32 || (ksize != 1 && ksize != 3) || Npad % 16 || Npad < Cout || (upsample && ((H | W) & 1)) ||
+        (stride == 2 && ksize != 3))
         return LGEN_ERR_BAD_ARG;
     if (B == 0 || H * W == 0) return 0;
     IgemmArgs a{(const uint16_t*)a_hi, (const uint16_t*)a_lo, (const uint16_t*)w_hi, (const uint16_t*)w_lo, bias, res, out,
-                H, W, Cin, Cout, Npad, ksize, upsample ? 1 : 0, out_nchw,
-                (long long)(H >> (upsample ? 1 : 0)) * (W >> (upsample ? 1 : 0)) * Cin, w_bstride, (long long)H * W * Cout, alpha};
+                H, W, Cin, Cout, Npad, ksize, upsample ? 1 : 0, out_nchw, stride,
+                stride == 2 ? (long long)(2 * H) * (2 * W) * Cin
+                            : (long long)(H >> (upsample ? 1 : 0)) * (W >> (upsample ? 1 : 0)) * Cin,
+                w_bstride, (long long)H * W * Cout, alpha};
     hipStream_t st = (hipStream_t)stream;
     if (g_igemm_variant == 2 && Npad % 64 == 0) return launch_igemm<4, 2, 1, true>(a, B, st);
     if (Npad % 128 == 0)                                            // 128 px x 128 ch

@@ -28,11 +28,12 @@ class _ConvW:
         cout, cin, k, _ = w.shape
         blk = 128 if cout >= 128 else (64 if cout >= 64 else 16)
         npad = (cout + blk - 1) // blk * blk
-        wt = torch.zeros(k * k, npad, cin, device=w.device)
-        wt[:, :cout] = w.permute(2, 3, 0, 1).reshape(k * k, cout, cin)
+        cpad = (cin + 31) // 32 * 32  # the igemm K-step is 32 input channels (RGB conv_in: 3 -> 32, zero weights)
+        wt = torch.zeros(k * k, npad, cpad, device=w.device)
+        wt[:, :cout, :cin] = w.permute(2, 3, 0, 1).reshape(k * k, cout, cin)
         self.hi, self.lo = _split_planes(wt)
         self.bias = conv.bias.detach().float().contiguous()
-        self.cin, self.cout, self.npad, self.k = cin, cout, npad, k
+        self.cin, self.cout, self.npad, self.k = cpad, cout, npad, k
 
 
 class _GNW:
@@ -74,6 +75,8 @@ class VQEngine:
         L.check(self.lib.lgen_vq_codebook_prep(L.ptr(cb), L.ptr(self.cbn), L.ptr(self.esq), self.n_e, self.e_dim,
                                                1 if self.l2 else 0, L.stream()), "codebook_prep")
         self._cb = cb
+        self._enc = None
+        self._model_ref = model
 
     @staticmethod
     def _sig(model):
@@ -101,10 +104,11 @@ class VQEngine:
         return hi, lo
 
     def _conv(self, planes, cw: _ConvW, B, H, W, upsample=False, res=None, out_nchw=False):
+        """H, W = OUTPUT size; upsample: False / True (nearest-2x input) / 2 (stride-2 Downsample conv)."""
         hi, lo = planes
         out = torch.empty(B * H * W * cw.cout, dtype=torch.float32, device=self.dev)
         L.check(self.lib.lgen_conv_igemm(L.ptr(hi), L.ptr(lo), L.ptr(cw.hi), L.ptr(cw.lo), L.ptr(cw.bias), L.ptr(res),
-                                         L.ptr(out), B, H, W, cw.cin, cw.cout, cw.npad, cw.k, 1 if upsample else 0,
+                                         L.ptr(out), B, H, W, cw.cin, cw.cout, cw.npad, cw.k, int(upsample),
                                          1 if out_nchw else 0, 0, 1.0, L.stream()), "conv_igemm")
         return out
 
@@ -199,6 +203,53 @@ class VQEngine:
                                         1 if self.l2 else 0, L.stream()), "vq_argmin")
         return out
 
+    # ---- encoder (vq_model.py:64-124, 41-45) ----------------------------------------------------------
+    def _encoder_weights(self):
+        if self._enc is None:
+            model = self._model_ref
+            enc = model.encoder
+            C, G = _ConvW, _GNW
+            res = lambda r: dict(n1=G(r.norm1), c1=C(r.conv1), n2=G(r.norm2), c2=C(r.conv2),
+                                 nin=C(r.nin_shortcut) if hasattr(r, "nin_shortcut") else None)
+            att = lambda a: dict(n=G(a.norm), q=C(a.q), k=C(a.k), v=C(a.v), p=C(a.proj_out))
+            self._enc = dict(
+                conv_in=C(enc.conv_in),
+                levels=[dict(res=[res(r) for r in blk.res], attn=[att(a) for a in blk.attn],
+                             down=C(blk.downsample.conv) if hasattr(blk, "downsample") else None) for blk in enc.conv_blocks],
+                mid=[res(enc.mid[0]), att(enc.mid[1]), res(enc.mid[2])],
+                norm_out=G(enc.norm_out), conv_out=C(enc.conv_out), quant=C(model.quant_conv))
+        return self._enc
+
     def encode(self, x):
-        raise NotImplementedError("VQ encoder convolutions (vq_model.py:105-124) are the next SURVEY section-8f row; "
-                                  "use quantize_indices(z) for the codebook argmin")
+        """VQModel.encode (eval): x fp32 [B, 3, H, W] -> (quant [B, e_dim, h, w], (None, None, None, 0),
+        (None, None, indices int64 [B*h*w])) like vq_model.py:41-45 / 254-259 with self.training False."""
+        E = self._encoder_weights()
+        B, Cx, H, W = x.shape
+        down = len(E["levels"]) - 1
+        if H % (1 << down) or W % (1 << down):
+            raise ValueError(f"image size {H}x{W} must be a multiple of {1 << down}")
+        cin = E["conv_in"].cin
+        xp = torch.zeros(B, H, W, cin, dtype=torch.float32, device=self.dev)  # NHWC, RGB padded to one 32-channel K-step
+        xp[..., :Cx] = x.to(self.dev, torch.float32).permute(0, 2, 3, 1)
+        h = self._conv(self._split(xp.reshape(-1), B, H * W, cin), E["conv_in"], B, H, W)
+        for lv in E["levels"]:
+            for bi, rp in enumerate(lv["res"]):
+                h = self._res(h, rp, B, H, W)
+                if lv["attn"]:
+                    h = self._attn(h, lv["attn"][bi], B, H, W)
+            if lv["down"] is not None:
+                c = lv["down"].cin
+                h = self._conv(self._split(h, B, H * W, c), lv["down"], B, H // 2, W // 2, upsample=2)
+                H, W = H // 2, W // 2
+        h = self._res(h, E["mid"][0], B, H, W)
+        h = self._attn(h, E["mid"][1], B, H, W)
+        h = self._res(h, E["mid"][2], B, H, W)
+        c = E["conv_out"].cin
+        h = self._conv(self._split(h, B, H * W, c, E["norm_out"], True), E["conv_out"], B, H, W)
+        zc = E["quant"].cin
+        z = self._conv(self._split(h, B, H * W, zc), E["quant"], B, H, W, out_nchw=True).view(B, self.e_dim, H, W)
+        idx = self.argmin(z)
+        emb = self.cbn if self.l2 else self._cb
+        quant = emb[idx].view(B, H, W, self.e_dim).permute(0, 3, 1, 2).contiguous()  # gather of codebook rows (no arithmetic)
+        self.last_latent = z
+        return quant, (None, None, None, 0), (None, None, idx)

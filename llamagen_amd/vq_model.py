@@ -204,7 +204,8 @@ class VQModel(nn.Module):
 
     @torch.no_grad()
     def encode(self, x):
-        """vq_model.py:41-45 -> (quant, (None, None, None, 0), (None, None, indices))."""
+        """vq_model.py:41-45 (eval): Encoder -> quant_conv -> VectorQuantizer.forward, all on the HIP kernels
+        -> (quant [B, e_dim, h, w], (None, None, None, 0), (None, None, indices int64 [B*h*w]))."""
         return self._eng().encode(x)
 
     def forward(self, input):

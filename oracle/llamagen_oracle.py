@@ -457,6 +457,41 @@ def vq_decoder(z: Tensor, sd: Dict[str, Tensor], ch_mult=(1, 1, 2, 2, 4), num_re
     return _conv(h, sd, pre + "conv_out", 1)
 
 
+def downsample(x: Tensor, sd: Dict[str, Tensor], pre: str) -> Tensor:
+    """Downsample.forward, vq_model.py:389-393: zero-pad right/bottom by one, conv3x3 stride 2, no padding."""
+    x = F.pad(x, (0, 1, 0, 1), mode="constant", value=0)
+    return F.conv2d(x, sd[pre + "conv.weight"], sd[pre + "conv.bias"], stride=2, padding=0)
+
+
+def vq_encoder(x: Tensor, sd: Dict[str, Tensor], ch_mult=(1, 1, 2, 2, 4), num_res_blocks: int = 2,
+               pre: str = "encoder.") -> Tensor:
+    """Encoder.forward, vq_model.py:105-124."""
+    nres = len(ch_mult)
+    h = _conv(x, sd, pre + "conv_in", 1)
+    for i_level in range(nres):
+        for i_block in range(num_res_blocks):
+            h = resnet_block(h, sd, f"{pre}conv_blocks.{i_level}.res.{i_block}.")
+            if i_level == nres - 1:
+                h = attn_block(h, sd, f"{pre}conv_blocks.{i_level}.attn.{i_block}.")
+        if i_level != nres - 1:
+            h = downsample(h, sd, f"{pre}conv_blocks.{i_level}.downsample.")
+    h = resnet_block(h, sd, pre + "mid.0.")
+    h = attn_block(h, sd, pre + "mid.1.")
+    h = resnet_block(h, sd, pre + "mid.2.")
+    h = swish(group_norm(h, sd[pre + "norm_out.weight"], sd[pre + "norm_out.bias"]))
+    return _conv(h, sd, pre + "conv_out", 1)
+
+
+def vq_encode(sd: Dict[str, Tensor], x: Tensor, ch_mult=(1, 1, 2, 2, 4)):
+    """VQModel.encode, vq_model.py:41-45 (eval): Encoder -> quant_conv 1x1 -> VectorQuantizer.forward.
+    Returns (latent z [B, e_dim, h, w] before quantisation, indices int64 [B*h*w], z_q [B, e_dim, h, w])."""
+    sd = {k: v.float() for k, v in sd.items()}
+    z = _conv(vq_encoder(x.float(), sd, ch_mult=ch_mult), sd, "quant_conv", 0)
+    idx = codebook_argmin(sd["quantize.embedding.weight"], z)
+    zq = get_codebook_entry(sd["quantize.embedding.weight"], idx, list(z.shape))
+    return z, idx, zq
+
+
 def vq_decode_code(sd: Dict[str, Tensor], code_b: Tensor, shape, channel_first: bool = True,
                    ch_mult=(1, 1, 2, 2, 4)) -> Tensor:
     """VQModel.decode_code -> decode, vq_model.py:47-55: gather, post_quant_conv 1x1, Decoder."""

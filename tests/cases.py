@@ -65,6 +65,10 @@ VQ_CASES = {
     "vq8_4x4": dict(kind="decode", vq="VQ-8", codebook_size=16384, embed_dim=8, wseed=4, rseed=23, batch=2, h=4, w=4),
     "argmin_6x6": dict(kind="argmin", vq="VQ-16", codebook_size=16384, embed_dim=8, wseed=3, rseed=24, batch=2, h=6, w=6),
     "argmin_24x24": dict(kind="argmin", vq="VQ-16", codebook_size=16384, embed_dim=8, wseed=5, rseed=25, batch=2, h=24, w=24),
+    # encode(): Encoder convs (stride-2 Downsample) -> quant_conv -> argmin; h, w = IMAGE size
+    "enc16_32x32": dict(kind="encode", vq="VQ-16", codebook_size=16384, embed_dim=8, wseed=6, rseed=26, batch=2, h=32, w=32),
+    "enc16_48x32": dict(kind="encode", vq="VQ-16", codebook_size=16384, embed_dim=8, wseed=6, rseed=27, batch=1, h=48, w=32),
+    "enc8_16x16": dict(kind="encode", vq="VQ-8", codebook_size=16384, embed_dim=8, wseed=7, rseed=28, batch=2, h=16, w=16),
 }
 
 
@@ -74,6 +78,8 @@ def make_vq_inputs(case):
     if case["kind"] == "decode":
         codes = torch.randint(0, case["codebook_size"], (B, h * w), generator=g)
         return dict(codes=codes, shape=[B, case["embed_dim"], h, w])
+    if case["kind"] == "encode":
+        return dict(x=torch.rand(B, 3, h, w, generator=g) * 2 - 1)
     z = torch.randn(B, case["embed_dim"], h, w, generator=g)
     return dict(z=z)
 

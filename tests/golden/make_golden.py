@@ -90,6 +90,14 @@ def run_vq_case(name, case):
         zq = vq.quantize.get_codebook_entry(idx, list(inp["z"].shape))
         arrs["zq_head"] = zq.numpy().astype(np.float32)[:1]
         print(f"vq_{name}: indices {idx.shape} head {idx[:6].tolist()}")
+    elif case["kind"] == "encode":
+        with torch.no_grad():
+            z = vq.quant_conv(vq.encoder(inp["x"]))
+            quant, _, (_, _, idx) = vq.encode(inp["x"])
+        arrs["latent"] = z.numpy().astype(np.float32)
+        arrs["indices"] = idx.numpy().astype(np.int64)
+        arrs["quant"] = quant.numpy().astype(np.float32)
+        print(f"vq_{name}: latent {tuple(z.shape)} indices head {idx[:6].tolist()}")
     np.savez_compressed(os.path.join(HERE, f"vq_{name}.npz"), **arrs)
 
 

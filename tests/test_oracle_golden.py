@@ -95,6 +95,19 @@ def test_oracle_vq_argmin(name):
     np.testing.assert_allclose(zq.numpy()[:1], gold["zq_head"], rtol=0, atol=1e-7)
 
 
+@pytest.mark.parametrize("name", [k for k, c in VQ_CASES.items() if c["kind"] == "encode"])
+def test_oracle_vq_encode(name):
+    """Encoder (stride-2 Downsample, AttnBlocks at the lowest level) -> quant_conv -> argmin vs the reference."""
+    case = VQ_CASES[name]
+    gold = load_golden("vq_" + name)
+    m, sd = build_vq_holder(case)
+    x = make_vq_inputs(case)["x"]
+    z, idx, zq = O.vq_encode(sd, x, ch_mult=tuple(m.config.encoder_ch_mult))
+    np.testing.assert_allclose(z.numpy(), gold["latent"], rtol=0, atol=2e-5)
+    np.testing.assert_array_equal(idx.numpy(), gold["indices"])
+    np.testing.assert_allclose(zq.numpy(), gold["quant"], rtol=0, atol=1e-6)
+
+
 def test_oracle_edge_cases():
     cb = torch.randn(64, 8)
     assert O.codebook_argmin(cb, torch.zeros(0, 8, 2, 2)).numel() == 0          # empty batch

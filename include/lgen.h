@@ -140,6 +140,14 @@ int lgen_conv_igemm(const void* a_hi, const void* a_lo, const void* w_hi, const 
                     const float* res, float* out, int B, int H, int W, int Cin, int Cout, int Npad, int ksize,
                     int upsample, int out_nchw, long long w_bstride, float alpha, void* stream);
 
+/* ---- post-processing of decoded samples (autoregressive/sample/sample_c2i_ddp.py:141-143) ------------- */
+
+/* F.interpolate(x, size=(Ho, Wo), mode='bicubic') (align_corners=False, A = -0.75): fp32 NCHW [BC][Hi][Wi] -> [BC][Ho][Wo]. */
+int lgen_resize_bicubic(const float* in_nchw, float* out_nchw, int BC, int Hi, int Wi, int Ho, int Wo, void* stream);
+
+/* torch.clamp(127.5 * x + 128.0, 0, 255).permute(0, 2, 3, 1).to(uint8): fp32 NCHW -> uint8 NHWC. */
+int lgen_to_uint8_hwc(const float* in_nchw, unsigned char* out_nhwc, int B, int C, int H, int W, void* stream);
+
 /* One-shot hint (per host thread): the next lgen_gemm / lgen_gemm_qkv_rope / lgen_attn_decode launch also
  * issues fire-and-forget reads of [next_weights, +bytes) -- the weight matrix of the kernel that follows it in
  * the decode chain -- so that the successor starts on a warm memory-side cache.  NULL clears it. */

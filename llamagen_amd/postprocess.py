@@ -1,0 +1,50 @@
+"""What the reference does with the decoded batch right after the hot path (sample_c2i_ddp.py:141-148,
+21-35): optional bicubic resize to the evaluation size, [-1, 1] float -> uint8 HWC, and the `.npz` pack of
+all samples that the FID evaluator reads.  The arithmetic runs in liblgen_hip.so (post_ops.hip); the PNG
+round trip of the reference (PIL, one file per image on a shared filesystem) is replaced by keeping the
+uint8 arrays in memory -- after the single RCCL gather they are already on rank 0."""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+@torch.no_grad()
+def resize_bicubic(samples: torch.Tensor, size: int) -> torch.Tensor:
+    """F.interpolate(samples, size=(size, size), mode='bicubic') -- sample_c2i_ddp.py:141-142."""
+    if samples.device.type != "cuda":
+        raise RuntimeError("llamagen_amd.postprocess runs only on an AMD GPU through the HIP library (no CPU fallback)")
+    B, C, H, W = samples.shape
+    x = samples.float().contiguous()
+    out = torch.empty(B, C, size, size, dtype=torch.float32, device=x.device)
+    L.check(L.lib().lgen_resize_bicubic(L.ptr(x), L.ptr(out), B * C, H, W, size, size, L.stream()), "resize_bicubic")
+    return out
+
+
+@torch.no_grad()
+def to_uint8_hwc(samples: torch.Tensor, image_size_eval: Optional[int] = None) -> torch.Tensor:
+    """sample_c2i_ddp.py:141-143: [resize ->] clamp(127.5 x + 128, 0, 255) -> uint8 [B, H, W, C] (on the device)."""
+    if samples.device.type != "cuda":
+        raise RuntimeError("llamagen_amd.postprocess runs only on an AMD GPU through the HIP library (no CPU fallback)")
+    if image_size_eval is not None and image_size_eval != samples.shape[-1]:
+        samples = resize_bicubic(samples, image_size_eval)
+    B, C, H, W = samples.shape
+    x = samples.float().contiguous()
+    out = torch.empty(B, H, W, C, dtype=torch.uint8, device=x.device)
+    L.check(L.lib().lgen_to_uint8_hwc(L.ptr(x), L.ptr(out), B, C, H, W, L.stream()), "to_uint8_hwc")
+    return out
+
+
+def save_npz(samples_uint8: torch.Tensor, npz_path: str, num: Optional[int] = None) -> str:
+    """create_npz_from_sample_folder (sample_c2i_ddp.py:21-35) without the PNG detour: [N, H, W, 3] uint8 ->
+    `arr_0` of an .npz, exactly what evaluations/c2i/evaluator.py reads."""
+    arr = samples_uint8.cpu().numpy() if isinstance(samples_uint8, torch.Tensor) else np.asarray(samples_uint8)
+    if num is not None:
+        arr = arr[:num]
+    assert arr.dtype == np.uint8 and arr.ndim == 4 and arr.shape[3] == 3, arr.shape
+    np.savez(npz_path, arr_0=arr)
+    return npz_path

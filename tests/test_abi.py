@@ -74,3 +74,16 @@ def test_registries_and_missing_gpu_is_loud():
         vq = VQ_models["VQ-16"]()
         with pytest.raises(RuntimeError):
             vq.decode_code(torch.zeros(1, 4, dtype=torch.long), [1, 8, 2, 2])
+        from llamagen_amd.postprocess import to_uint8_hwc
+        with pytest.raises(RuntimeError):
+            to_uint8_hwc(torch.zeros(1, 3, 4, 4))
+
+
+def test_save_npz_layout(tmp_path):
+    """create_npz_from_sample_folder's output format (sample_c2i_ddp.py:21-35): one uint8 [N, H, W, 3] array `arr_0`."""
+    import numpy as np
+    from llamagen_amd.postprocess import save_npz
+    arr = (np.arange(2 * 4 * 4 * 3) % 256).astype(np.uint8).reshape(2, 4, 4, 3)
+    p = save_npz(torch.from_numpy(arr), str(tmp_path / "s.npz"))
+    z = np.load(p)
+    assert list(z.keys()) == ["arr_0"] and np.array_equal(z["arr_0"], arr)

@@ -213,3 +213,29 @@ def test_encode_decode_round_trip_256px():
     assert (m.decode(quant) - img).abs().max().item() < 1e-5
     _, _, (_, _, idx2) = m.encode(x)
     assert torch.equal(idx, idx2)
+
+
+@pytest.mark.parametrize("B,Hi,Ho", [(2, 384, 256), (1, 24, 16), (3, 20, 32), (1, 7, 7)])
+def test_postprocess_resize_and_uint8(B, Hi, Ho):
+    """sample_c2i_ddp.py:141-143 on the HIP path vs torch's own CPU kernels (the reference's arithmetic):
+    bicubic within fp32 rounding, uint8 identical except where the float lands within rounding of an integer."""
+    from llamagen_amd.postprocess import resize_bicubic, to_uint8_hwc
+    dev = _dev()
+    x = _rand((B, 3, Hi, Hi), 11) * 0.6
+    r = resize_bicubic(x.to(dev), Ho)
+    ref = F.interpolate(x, size=(Ho, Ho), mode="bicubic")
+    assert (r.cpu() - ref).abs().max().item() < 2e-6 * max(1.0, ref.abs().max().item())
+    u = to_uint8_hwc(x.to(dev), Ho)
+    uref = O.to_uint8_hwc(ref)
+    assert u.dtype == torch.uint8 and tuple(u.shape) == (B, Ho, Ho, 3)
+    d = (u.cpu().int() - uref.int()).abs()
+    assert d.max().item() <= 1 and (d > 0).float().mean().item() < 1e-3
+    assert torch.equal(to_uint8_hwc(ref.to(dev)).cpu(), uref)  # same float input -> identical bytes
+
+
+def test_postprocess_uint8_matches_reference_golden():
+    """The goldens hold the reference's own uint8 HWC conversion of its decoded image."""
+    from llamagen_amd.postprocess import to_uint8_hwc
+    gold = load_golden("vq_vq16_4x4")
+    img = torch.from_numpy(gold["image"]).to(_dev())
+    assert np.array_equal(to_uint8_hwc(img).cpu().numpy(), gold["uint8"])

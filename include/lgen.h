@@ -72,20 +72,22 @@ int lgen_gemm_max_kw(int epilogue_kind, int fused_norm, int mt, int nt);
 
 /* Attention.forward front half (gpt.py:214-226): [attention_norm, gpt.py:254 +] wqkv GEMM +
  * apply_rotary_emb(q,k) (gpt.py:420-430) + KVCache.update at *pos_ptr (gpt.py:177-185).
- * q_out [MTs*16][H][hdp]; caches [B2][H][S8][hdp]; freqs [P][hd/2][2] fp32 from
- * precompute_freqs_cis_2d (gpt.py:404-417); norm_w / ssq_in / ssq_parts / eps as in lgen_gemm. */
+ * q_out [MTs*16][H][hdp]; caches [B2][H][S8] rows of hdp elements, kv_row_stride elements apart (0 = hdp;
+ * 2*hdp with v_cache = k_cache + hdp is the interleaved K|V slab the engine uses: one HBM stream per (b, h));
+ * freqs [P][hd/2][2] fp32 from precompute_freqs_cis_2d (gpt.py:404-417); norm_w / ssq_in / ssq_parts / eps as
+ * in lgen_gemm. */
 int lgen_gemm_qkv_rope(const void* wp, const void* xp, void* q_out, void* k_cache, void* v_cache, const float* freqs,
-                       const int* pos_ptr, int M, int MTs, int d, int n_head, int hd, int hdp, int S8, int dtype,
-                       int mt, int nt, int kw, const void* norm_w, const float* ssq_in, int ssq_parts, float eps,
-                       void* stream);
+                       const int* pos_ptr, int M, int MTs, int d, int n_head, int hd, int hdp, int S8,
+                       int kv_row_stride, int dtype, int mt, int nt, int kw, const void* norm_w, const float* ssq_in,
+                       int ssq_parts, float eps, void* stream);
 
 /* Attention.forward back half (gpt.py:229-236): repeat_interleave + math-backend SDPA with
  * causal_mask[:, pos] -- here: single-query attention over the first *pos_ptr+1 cache slots.
  * mask: null = pure causal, else the reference's causal_mask [B2][S8][S8] (1 byte per entry, as
  * modified by generate.py:154-163 for t2i emb_masks); row *pos_ptr of it gates the keys. */
 int lgen_attn_decode(const void* q, const void* k_cache, const void* v_cache, void* out_packed, const int* pos_ptr,
-                     const unsigned char* mask, int B2, int MTs, int n_head, int hd, int hdp, int S8, int dtype,
-                     void* stream);
+                     const unsigned char* mask, int B2, int MTs, int n_head, int hd, int hdp, int S8, int kv_row_stride,
+                     int dtype, void* stream);
 
 /* generate.py:79-86,94-99 (CFG mix) + :57-66 sample() + :16-54 top_k_top_p_filtering +
  * torch.multinomial(1) == argmax(p / noise).  logits [>=2B][V] storage dtype (rows [0,B) cond,
@@ -154,7 +156,7 @@ int lgen_to_uint8_hwc(const float* in_nchw, unsigned char* out_nhwc, int B, int 
 int lgen_prefetch_hint(const void* next_weights, long long bytes);
 
 /* ---- tuning knobs (process-wide kernel variant selection; defaults are the measured-best ones) ---- */
-int lgen_set_attn_variant(int v);  /* 1 (default): 2 K/V loads per buffer, all B2*H workgroups resident; 0: 4 */
+int lgen_set_attn_variant(int v);  /* (K/V loads per buffer, waves per (b,h)): 2 (default) = (2,2); 1 = (2,4); 0 = (4,4); 3 = (4,2) */
 int lgen_set_igemm_variant(int v); /* 0 (default): 128x128 tile, 1 staging set; 1: 2 sets; 2: 128x64 tiles, 2 sets */
 
 #ifdef __cplusplus

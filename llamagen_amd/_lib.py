@@ -31,13 +31,13 @@ SIGNATURES = {
     "lgen_rmsnorm": [_P, _P, _P, _I, _I, _F, _I, _P],
     "lgen_gemm": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _F, _P, _P],
     "lgen_gemm_max_kw": [_I, _I, _I, _I],
-    "lgen_gemm_qkv_rope": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _F, _P],
+    "lgen_gemm_qkv_rope": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _F, _P],
     "lgen_resize_bicubic": [_P, _P, _I, _I, _I, _I, _I, _P],
     "lgen_to_uint8_hwc": [_P, _P, _I, _I, _I, _I, _P],
     "lgen_prefetch_hint": [_P, _c.c_longlong],
     "lgen_set_attn_variant": [_I],
     "lgen_set_igemm_variant": [_I],
-    "lgen_attn_decode": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "lgen_attn_decode": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "lgen_sample": [_P, _P, _c.c_longlong, _P, _P, _P, _I, _I, _I, _I, _F, _I, _F, _I, _F, _I, _I, _P],
     "lgen_advance_state": [_P, _P],
     "lgen_vq_codebook_prep": [_P, _P, _P, _I, _I, _I, _P],

@@ -19,6 +19,7 @@ struct GemmArgs {
     float* ssq_out;      // RES: [N/16][MTs*16] partial sums of squares of the new rows (nullable)
     int N, KCH, MTs, M;
     int d, hd, hdp, H, S8;
+    int kvs;             // QKV: elements between consecutive cache rows (hdp, or 2*hdp for an interleaved K|V slab)
     int parts;
     float eps, inv_k;
     const char* pf;      // weights of the NEXT kernel of the chain (nullable): pulled towards the memory-side cache
@@ -43,8 +44,12 @@ LGEN_DEV unsigned prefetch_lines(const char* base, long long bytes, int part, in
     }
     return junk;
 }
-// vmcnt(0): free when the wave has consumed its own (younger) loads; required for waves that had none
-LGEN_DEV void prefetch_retire(unsigned token) { asm volatile("s_waitcnt vmcnt(0)" ::"v"(token) : "memory"); }
+// vmcnt(0): free when the wave has consumed its own (younger) loads; required for waves that had none.
+// Only when a prefetch was actually issued (uniform branch): an unconditional wait would make idle attention
+// waves sit out their speculative first K/V loads.
+LGEN_DEV void prefetch_retire(const char* base, unsigned token) {
+    if (base) asm volatile("s_waitcnt vmcnt(0)" ::"v"(token) : "memory");
+}
 
 LGEN_DEV float silu_f(float x) { return x / (1.0f + expf(-x)); }
 LGEN_DEV float gelu_tanh_f(float x) {
@@ -131,7 +136,7 @@ LGEN_DEV void epilogue(const GemmArgs& a, int nt, int mt, int lane, f32x4_t v, f
             D::st4(a.out, ((size_t)m * a.H + head) * a.hdp + dd, x0, x1, x2, x3);
         } else {
             void* cache = sec == 1 ? a.kc : a.vc;
-            D::st4(cache, (((size_t)m * a.H + head) * a.S8 + pos) * a.hdp + dd, x0, x1, x2, x3);
+            D::st4(cache, (((size_t)m * a.H + head) * a.S8 + pos) * a.kvs + dd, x0, x1, x2, x3);
         }
     }
 }

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(512) void gemm_normpre_kernel(GemmArgs a) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) acc[j][i] = D::mma(A[c][j], B[c][i], acc[j][i]);
 
-    prefetch_retire(pf_token);
+    prefetch_retire(a.pf, pf_token);
 
     if (KW == 1) {
 #pragma unroll

@@ -148,7 +148,7 @@ __global__ __launch_bounds__((gemm_max_threads<MT, NT, NORM, EPI>())) void gemm_
 #undef LGEN_LOAD
 #undef LGEN_MMA
 
-    prefetch_retire(pf_token);
+    prefetch_retire(a.pf, pf_token);
 
     if (KW == 1) {
 #pragma unroll
@@ -311,8 +311,8 @@ extern "C" int lgen_gemm(const void* wp, const void* xp, void* out, int M, int M
 
 extern "C" int lgen_gemm_qkv_rope(const void* wp, const void* xp, void* q_out, void* k_cache, void* v_cache,
                                   const float* freqs, const int* pos_ptr, int M, int MTs, int d, int n_head, int hd,
-                                  int hdp, int S8, int dtype, int mt, int nt, int kw, const void* norm_w,
-                                  const float* ssq_in, int ssq_parts, float eps, void* stream) {
+                                  int hdp, int S8, int kv_row_stride, int dtype, int mt, int nt, int kw,
+                                  const void* norm_w, const float* ssq_in, int ssq_parts, float eps, void* stream) {
     const int kcsz = dtype == LGEN_BF16 ? 32 : 16;
     if (d % kcsz || (3 * d) % 16 || hd % 4 || d != n_head * hd || M > MTs * 16) return LGEN_ERR_BAD_ARG;
     GemmArgs a{};
@@ -320,6 +320,8 @@ extern "C" int lgen_gemm_qkv_rope(const void* wp, const void* xp, void* q_out, v
     a.freqs = freqs; a.pos_ptr = pos_ptr;
     a.N = 3 * d; a.KCH = d / kcsz; a.MTs = MTs; a.M = M;
     a.d = d; a.hd = hd; a.hdp = hdp; a.H = n_head; a.S8 = S8;
+    a.kvs = kv_row_stride > 0 ? kv_row_stride : hdp;
+    if (a.kvs < hdp) return LGEN_ERR_BAD_ARG;
     a.nw = (const uint4*)norm_w; a.ssq_in = ssq_in; a.parts = ssq_parts; a.eps = eps; a.inv_k = 1.0f / (float)d;
     lgen_take_prefetch_hint(&a.pf, &a.pf_bytes);
     return dispatch_norm<EPI_QKV>(a, dtype, mt, nt, kw, (hipStream_t)stream);

@@ -203,12 +203,12 @@ struct AttnArgs {
     const unsigned char* mask;  // null (pure causal) or causal_mask [B2][S8][S8] bytes: row `pos` is read
     int H, hd, hdp, S8, MTs;
     float sf;            // sqrt(1/sqrt(hd))
+    int kvs;             // elements between consecutive cache rows (hdp, or 2*hdp for an interleaved K|V slab)
     const char* pf;      // next kernel's weights (wo), see prefetch_lines in gemm_epilogue.h
     long long pf_bytes;
 };
 
-#define ATT_NW 4
-template <typename D, int LPK, int ATT_CH>
+template <typename D, int LPK, int ATT_CH, int ATT_NW>
 __global__ __launch_bounds__(64 * ATT_NW, (ATT_CH <= 2 ? 4 : 2)) void attn_decode_kernel(AttnArgs a) {
     constexpr int KPL = 64 / LPK;            // keys per wave-load
     constexpr int EPL = D::EPL;
@@ -221,8 +221,9 @@ __global__ __launch_bounds__(64 * ATT_NW, (ATT_CH <= 2 ? 4 : 2)) void attn_decod
     const int part = lane % LPK, kin = lane / LPK;
     const size_t rowbase = ((size_t)b * a.H + h) * a.S8;
     const int lpr = a.hdp / EPL;             // 16-byte pieces per key row (== LPK)
-    const uint4* kp = (const uint4*)a.kc + rowbase * lpr + part;
-    const uint4* vp = (const uint4*)a.vc + rowbase * lpr + part;
+    const int rpr = a.kvs / EPL;             // 16-byte pieces between consecutive rows of one cache
+    const uint4* kp = (const uint4*)a.kc + rowbase * rpr + part;
+    const uint4* vp = (const uint4*)a.vc + rowbase * rpr + part;
     const int smax = a.S8 - 1;
 
     const unsigned pf_token = prefetch_lines(a.pf, a.pf_bytes, blockIdx.x * ATT_NW + wv, gridDim.x * ATT_NW, lane);
@@ -232,8 +233,8 @@ __global__ __launch_bounds__(64 * ATT_NW, (ATT_CH <= 2 ? 4 : 2)) void attn_decod
         _Pragma("unroll") for (int j = 0; j < ATT_CH; ++j) {                \
             int kk = (g) * GK + j * KPL + kin;                              \
             kk = kk < smax ? kk : smax;                                     \
-            KB[j] = kp[(size_t)kk * lpr];                                   \
-            VB[j] = vp[(size_t)kk * lpr];                                   \
+            KB[j] = kp[(size_t)kk * rpr];                                   \
+            VB[j] = vp[(size_t)kk * rpr];                                   \
         }                                                                   \
     }
     // group g of this wave: g = wv, wv + NW, ...; first group requested before pos is known
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(64 * ATT_NW, (ATT_CH <= 2 ? 4 : 2)) void attn_decod
     }
 #undef ATT_LOAD
 #undef ATT_COMPUTE
-    prefetch_retire(pf_token);
+    prefetch_retire(a.pf, pf_token);
     // combine the KPL key groups of this wave (lanes with equal `part`)
 #pragma unroll
     for (int o = LPK; o < 64; o <<= 1) {
@@ -308,8 +309,7 @@ __global__ __launch_bounds__(64 * ATT_NW, (ATT_CH <= 2 ? 4 : 2)) void attn_decod
     }
     if (lane == 0) { s_m[wv] = m_run; s_l[wv] = l_run; }
     __syncthreads();
-    const int t = threadIdx.x;
-    if (t < a.hd) {
+    for (int t = threadIdx.x; t < a.hd; t += 64 * ATT_NW) {
         float M = s_m[0];
 #pragma unroll
         for (int i = 1; i < ATT_NW; ++i) M = fmaxf(M, s_m[i]);
@@ -325,27 +325,32 @@ __global__ __launch_bounds__(64 * ATT_NW, (ATT_CH <= 2 ? 4 : 2)) void attn_decod
     }
 }
 
-// variant: keys in flight per wave = 2 buffers x ATT_CH loads; 1 = default (ATT_CH 2: every workgroup of
-// a B2 x H = 1024 grid is resident at once, measured faster at every position), 0 = ATT_CH 4
-static int g_attn_variant = 1;
+// variant (ATT_CH K/V loads per buffer, waves per (b, h) workgroup): 2 = default (2, 2): 128-thread workgroups,
+// every workgroup of a B2 x H = 1024 grid resident at once, lowest fixed cost (4.4 us at kv_len 1 vs 6.1 us with
+// 4 waves) and the same 6.4 TB/s incremental rate at long kv_len; 1 = (2, 4); 0 = (4, 4); 3 = (4, 2)
+static int g_attn_variant = 2;
 extern "C" int lgen_set_attn_variant(int v) { g_attn_variant = v; return 0; }
 
 extern "C" int lgen_attn_decode(const void* q, const void* k_cache, const void* v_cache, void* out_packed,
                                 const int* pos_ptr, const unsigned char* mask, int B2, int MTs, int n_head,
-                                int hd, int hdp, int S8, int dtype, void* stream) {
-    AttnArgs a{q, k_cache, v_cache, out_packed, pos_ptr, mask, n_head, hd, hdp, S8, MTs, 0.f, nullptr, 0};
+                                int hd, int hdp, int S8, int kv_row_stride, int dtype, void* stream) {
+    AttnArgs a{q, k_cache, v_cache, out_packed, pos_ptr, mask, n_head, hd, hdp, S8, MTs, 0.f,
+               kv_row_stride > 0 ? kv_row_stride : hdp, nullptr, 0};
     lgen_take_prefetch_hint(&a.pf, &a.pf_bytes);
     a.sf = sqrtf(1.0f / sqrtf((float)hd));
     hipStream_t st = (hipStream_t)stream;
     const int epl = dtype == LGEN_BF16 ? 8 : 4;
     if (dtype != LGEN_BF16 && dtype != LGEN_F32) return LGEN_ERR_BAD_ARG;
-    if (hdp % epl || hd > hdp || hd > 64 * ATT_NW || B2 > MTs * 16 || S8 < 1) return LGEN_ERR_BAD_ARG;
+    if (hdp % epl || hd > hdp || B2 > MTs * 16 || S8 < 1 || a.kvs < hdp || a.kvs % epl) return LGEN_ERR_BAD_ARG;
     const int lpk = hdp / epl;
-    dim3 grid(B2 * n_head), block(64 * ATT_NW);
+    const int nw = g_attn_variant >= 2 ? 2 : 4;
+    dim3 grid(B2 * n_head), block(64 * nw);
 #define LGEN_ATT(DT, L)                                                                              \
     do {                                                                                             \
-        if (g_attn_variant == 1) hipLaunchKernelGGL((attn_decode_kernel<DT, L, 2>), grid, block, 0, st, a); \
-        else hipLaunchKernelGGL((attn_decode_kernel<DT, L, 4>), grid, block, 0, st, a);              \
+        if (g_attn_variant == 1) hipLaunchKernelGGL((attn_decode_kernel<DT, L, 2, 4>), grid, block, 0, st, a);      \
+        else if (g_attn_variant == 2) hipLaunchKernelGGL((attn_decode_kernel<DT, L, 2, 2>), grid, block, 0, st, a); \
+        else if (g_attn_variant == 3) hipLaunchKernelGGL((attn_decode_kernel<DT, L, 4, 2>), grid, block, 0, st, a); \
+        else hipLaunchKernelGGL((attn_decode_kernel<DT, L, 4, 4>), grid, block, 0, st, a);                          \
     } while (0)
     if (dtype == LGEN_BF16 && lpk == 8) LGEN_ATT(BF16, 8);
     else if (dtype == LGEN_BF16 && lpk == 16) LGEN_ATT(BF16, 16);

@@ -126,9 +126,18 @@ class DecodeEngine:
         self.mt = min(mts, 4)  # m-tiles per workgroup (1, 2 or 4; MTs is 1, 2, 4 or a multiple of 8)
         dev, dt = self.dev, dtype
         z = lambda *s, dtype=dt: torch.zeros(*s, dtype=dtype, device=dev)
-        # KV slabs (gpt.py:170-185); hd padded to 64/128 so a key row is a power-of-two lane group
-        self.k_cache = z(self.L, max_batch, self.H, S8, self.hdp)
-        self.v_cache = z(self.L, max_batch, self.H, S8, self.hdp)
+        # KV slabs (gpt.py:170-185); hd padded to 64/128 so a key row is a power-of-two lane group.  Two separate
+        # slabs by default; LGEN_KV_INTERLEAVE=1 puts the K and V row of a slot next to each other
+        # ([.., S8, 2, hdp], row stride 2*hdp: one HBM stream per (b, h) instead of two) -- measured 1.4 % SLOWER
+        # in the decode attention at kv_len 576 on MI355X, so it stays an option of the kernels' row-stride argument.
+        if os.environ.get("LGEN_KV_INTERLEAVE") == "1":
+            self.kv_slab = z(self.L, max_batch, self.H, S8, 2, self.hdp)
+            self.k_cache, self.v_cache = self.kv_slab[..., 0, :], self.kv_slab[..., 1, :]
+            self.kvs = 2 * self.hdp
+        else:
+            self.k_cache = z(self.L, max_batch, self.H, S8, self.hdp)
+            self.v_cache = z(self.L, max_batch, self.H, S8, self.hdp)
+            self.kvs = self.hdp
         self.causal_mask = torch.tril(torch.ones(S8, S8, dtype=torch.bool, device=dev)).unsqueeze(0).repeat(max_batch, 1, 1)
         grid = int(cfg.block_size ** 0.5)
         self.freqs_cis = precompute_freqs_cis_2d(grid, self.hd, cfg.rope_base, self.T).to(dev).contiguous()
@@ -263,14 +272,14 @@ class DecodeEngine:
                 x_in, nw = self.xnp, None
             L.check(lib.lgen_gemm_qkv_rope(L.ptr(w["wqkv"]), L.ptr(x_in), L.ptr(self.qbuf), L.ptr(self.k_cache[i]),
                                            L.ptr(self.v_cache[i]), L.ptr(self.freqs_cis), pos_ptr, M, mts, d, H, hd, hdp,
-                                           S8, dt, tq[0], tq[1], tq[2], L.ptr(nw), L.ptr(ssq), self.ssq_parts, self.eps, st),
+                                           S8, self.kvs, dt, tq[0], tq[1], tq[2], L.ptr(nw), L.ptr(ssq), self.ssq_parts, self.eps, st),
                     "gemm_qkv_rope")
             if self._prof is not None:  # bench.py roofline leg: HIP events on the launch stream
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
             hint(w["wo"])
             L.check(lib.lgen_attn_decode(L.ptr(self.qbuf), L.ptr(self.k_cache[i]), L.ptr(self.v_cache[i]), L.ptr(self.ap),
-                                         pos_ptr, L.ptr(pm), M, mts, H, hd, hdp, S8, dt, st), "attn_decode")
+                                         pos_ptr, L.ptr(pm), M, mts, H, hd, hdp, S8, self.kvs, dt, st), "attn_decode")
             if self._prof is not None:
                 e1.record()
                 self._prof["events"].append((e0, e1))

@@ -191,8 +191,9 @@ def test_fused_rmsnorm_chain(dt, M, d, F, tiles):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("interleave", [False, True])
 @pytest.mark.parametrize("B2,H,hd,grid,pos", [(2, 4, 64, 4, 0), (2, 4, 64, 4, 7), (33, 16, 64, 24, 300), (3, 8, 100, 4, 16)])
-def test_qkv_rope_append_and_attention(dt, B2, H, hd, grid, pos):
+def test_qkv_rope_append_and_attention(dt, B2, H, hd, grid, pos, interleave):
     """wqkv GEMM + RoPE + cache append, then decode attention over the cache, vs the oracle."""
     from llamagen_amd.engine import pack_act, pack_weight, precompute_freqs_cis_2d, unpack_act
     L, dev = _L(), _dev()
@@ -207,15 +208,20 @@ def test_qkv_rope_append_and_attention(dt, B2, H, hd, grid, pos):
     vcache = _rand((B2, H, S8, hd), dt, 12)
     mts = (B2 + 15) // 16
     mts = {3: 4}.get(mts, mts)
-    kc_d = torch.zeros(B2, H, S8, hdp, dtype=dt, device=dev)
-    vc_d = torch.zeros(B2, H, S8, hdp, dtype=dt, device=dev)
+    if interleave:  # the engine's layout: K and V row of a slot adjacent, row stride 2 * hdp
+        slab = torch.zeros(B2, H, S8, 2, hdp, dtype=dt, device=dev)
+        kc_d, vc_d, KVS = slab[..., 0, :], slab[..., 1, :], 2 * hdp
+    else:
+        kc_d = torch.zeros(B2, H, S8, hdp, dtype=dt, device=dev)
+        vc_d = torch.zeros(B2, H, S8, hdp, dtype=dt, device=dev)
+        KVS = 0
     kc_d[..., :hd] = kcache.to(dev)
     vc_d[..., :hd] = vcache.to(dev)
     q_d = torch.zeros(mts * 16, H, hdp, dtype=dt, device=dev)
     state = torch.tensor([pos, 0], dtype=torch.int32, device=dev)
     wp, xp, fr_d = pack_weight(w.to(dev)), pack_act(x.to(dev), mts), freqs.to(dev)  # keep alive across the launch
     L.check(L.lib().lgen_gemm_qkv_rope(L.ptr(wp), L.ptr(xp), L.ptr(q_d), L.ptr(kc_d),
-                                       L.ptr(vc_d), L.ptr(fr_d), L.ptr(state), B2, mts, d, H, hd, hdp, S8, code,
+                                       L.ptr(vc_d), L.ptr(fr_d), L.ptr(state), B2, mts, d, H, hd, hdp, S8, KVS, code,
                                        min(mts, 4), 1, 4, 0, 0, 0, 0.0, L.stream()), "qkv")
     qkv = O.linear(x.float(), w.float(), dt)
     xq, xk, xv = qkv.split([d, d, d], dim=-1)
@@ -234,7 +240,7 @@ def test_qkv_rope_append_and_attention(dt, B2, H, hd, grid, pos):
     vc_d[..., :hd] = vref.to(dt).to(dev)
     q_d[:B2, :, :hd] = xq[:, 0].to(dt).to(dev)
     kcd = 32 if dt == torch.bfloat16 else 16
-    for use_mask, variant in ((False, 0), (True, 0), (False, 1), (True, 1)):
+    for use_mask, variant in ((False, 0), (True, 0), (False, 1), (True, 1), (False, 2), (True, 3)):
         L.lib().lgen_set_attn_variant(variant)
         mask = torch.tril(torch.ones(S8, S8, dtype=torch.bool)).unsqueeze(0).repeat(B2, 1, 1)
         if use_mask:
@@ -244,10 +250,10 @@ def test_qkv_rope_append_and_attention(dt, B2, H, hd, grid, pos):
         out = torch.zeros(d // kcd, mts, 64, kcd // 4, dtype=dt, device=dev)
         md = mask.to(dev).contiguous() if use_mask else None
         L.check(L.lib().lgen_attn_decode(L.ptr(q_d), L.ptr(kc_d), L.ptr(vc_d), L.ptr(out), L.ptr(state), L.ptr(md), B2, mts, H,
-                                         hd, hdp, S8, code, L.stream()), "attn")
+                                         hd, hdp, S8, KVS, code, L.stream()), "attn")
         ref = O.sdpa_math(xq.transpose(1, 2), kref, vref, mask[:, None, pos:pos + 1], dt)  # [B,H,1,hd]
         _close(unpack_act(out, B2), ref.transpose(1, 2).reshape(B2, d), dt, f"attn mask={use_mask} variant={variant}")
-    L.lib().lgen_set_attn_variant(1)
+    L.lib().lgen_set_attn_variant(2)
 
 
 @pytest.mark.parametrize("dt", DTYPES)

@@ -74,7 +74,7 @@ def main(name="GPT-L", B=32, img=384):
                     for w in ([e.layers[0]] * nl if hot else e.layers):
                         if kind == "qkv":
                             L.check(lib.lgen_gemm_qkv_rope(L.ptr(w["wqkv"]), L.ptr(e.hp), L.ptr(e.qbuf), L.ptr(e.k_cache[0]), L.ptr(e.v_cache[0]),
-                                                           L.ptr(e.freqs_cis), L.ptr(e.state), M, mts, d, H, hd, hdp, S8, dt, tl[0], tl[1], tl[2],
+                                                           L.ptr(e.freqs_cis), L.ptr(e.state), M, mts, d, H, hd, hdp, S8, e.kvs, dt, tl[0], tl[1], tl[2],
                                                            L.ptr(w["an"]) if norm else 0, L.ptr(e.ssq), e.ssq_parts, e.eps, st()), "qkv")
                         elif kind == "wo":
                             e.gemm(w["wo"], e.ap, e.hp, M, mts, d, d, L.EPI_RES, tl, ssq_out=e.ssq)
@@ -90,16 +90,16 @@ def main(name="GPT-L", B=32, img=384):
     for tl in [(4, 2, 8), (4, 4, 8), (4, 4, 4)]:
         report(f"head {tl} norm=True", lambda: [e.gemm(e.out_w, e.hp, e.logits, M, mts, V, d, L.EPI_ROWS, tl, norm_w=e.norm_w) for _ in range(8)], 8, V * d * 2)
     report("rmsnorm standalone", lambda: [L.check(lib.lgen_rmsnorm(L.ptr(e.hp), L.ptr(e.norm_w), L.ptr(e.xnp), mts, d, e.eps, dt, st()), "n") for _ in range(48)], 48)
-    for variant in (0, 1):
+    for variant in (1, 2, 3):
         lib.lgen_set_attn_variant(variant)
-        for pos in (8, 144, 288, 575):
+        for pos in (0, 64, 144, 288, 575):
             e.state.copy_(torch.tensor([pos, pos], dtype=torch.int32, device=dev))
             def fa():
                 for i in range(nl):
                     L.check(lib.lgen_attn_decode(L.ptr(e.qbuf), L.ptr(e.k_cache[i]), L.ptr(e.v_cache[i]), L.ptr(e.ap), L.ptr(e.state), 0,
-                                                 M, mts, H, hd, hdp, S8, dt, st()), "attn")
+                                                 M, mts, H, hd, hdp, S8, e.kvs, dt, st()), "attn")
             report(f"attn variant {variant} pos {pos}", fa, nl, (pos + 1) * 2 * H * hd * 2 * M)
-    lib.lgen_set_attn_variant(1)
+    lib.lgen_set_attn_variant(2)
     sp = dict(use_cfg=True, cfg_scale=4.0, cfg_interval=-1, temperature=1.0, top_k=2000, top_p=1.0, sample_logits=True)
     e.noise = torch.empty(8, B, V, device=dev).exponential_(1.0)
     e.state.zero_()

@@ -70,13 +70,16 @@ def main(name="GPT-L", B=32, img=384, what="all"):
     print("default tiles:", {k: eng._tiles(k, *nk) for k, nk in dict(qkv=(3 * d, d), wo=(d, d), w13=(2 * F, d), w2=(d, F), head=(V, d)).items()})
     # interleaved A/B (run-to-run drift on this box is several %): every config is measured in every round
     configs = {
-        "prefetch off": dict(fuse=True, tiles={}, pf=False),
-        "prefetch on": dict(fuse=True, tiles={}, pf=True),
+        "default (attn variant 2)": dict(fuse=True, tiles={}, attn=2),
+        "attn variant 1": dict(fuse=True, tiles={}, attn=1),
+        "w13(1,2,8)": dict(fuse=True, tiles={"w13": (1, 2, 8)}, attn=2),
+        "w13(1,4,8)": dict(fuse=True, tiles={"w13": (1, 4, 8)}, attn=2),
     }
-    for rnd in range(3):
+    for rnd in range(2):
         for tag, c in configs.items():
             eng.fuse_norm = c["fuse"]
-            eng.prefetch = c.get("pf", True)
+            eng.prefetch = c.get("pf", False)
+            L.lib().lgen_set_attn_variant(c.get("attn", 2))
             eng.tile_override = dict(c["tiles"])
             try:
                 row(f"r{rnd} {tag}")

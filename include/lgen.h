@@ -89,6 +89,22 @@ int lgen_attn_decode(const void* q, const void* k_cache, const void* v_cache, vo
                      const unsigned char* mask, int B2, int MTs, int n_head, int hd, int hdp, int S8, int kv_row_stride,
                      int dtype, void* stream);
 
+/* ---- prefix prefill (t2i: all T = cls_token_num caption positions of all B2 rows per layer at once; rows
+ * r = t * B2 + b of the packed activations; generate.py:77-86 + gpt.py:348-349 with emb_masks folded into
+ * causal_mask, generate.py:154-163) ---- */
+
+/* packed wqkv output (lgen_gemm EPI_PACKED, width 3d, R = B2*T rows) -> apply_rotary_emb(q, k) at position
+ * pos0 + t (gpt.py:220-226, 420-430); q rows [R][H][hdp]; K/V into slot pos0 + t of cache row b (gpt.py:177-185). */
+int lgen_rope_append_prefill(const void* qkv_packed, void* q_rows, void* k_cache, void* v_cache, const float* freqs, int R,
+                             int B2, int MTs, int d, int n_head, int hd, int hdp, int S8, int kv_row_stride, int pos0,
+                             int dtype, void* stream);
+
+/* masked causal attention of the prefix onto itself (gpt.py:229-236, math-SDPA semantics): query row (b, t)
+ * sees keys s <= t with mask[b][t][s] != 0 (mask = causal_mask [B2][S8][S8] bytes or null); out = XP of width d. */
+int lgen_attn_prefill(const void* q_rows, const void* k_cache, const void* v_cache, void* out_packed,
+                      const unsigned char* mask, int T, int B2, int MTs, int n_head, int hd, int hdp, int S8,
+                      int kv_row_stride, int dtype, void* stream);
+
 /* generate.py:79-86,94-99 (CFG mix) + :57-66 sample() + :16-54 top_k_top_p_filtering +
  * torch.multinomial(1) == argmax(p / noise).  logits [>=2B][V] storage dtype (rows [0,B) cond,
  * [B,2B) uncond when use_cfg); noise fp32 Exp(1) draws: row b of this call is at

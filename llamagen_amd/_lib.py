@@ -38,6 +38,8 @@ SIGNATURES = {
     "lgen_set_attn_variant": [_I],
     "lgen_set_igemm_variant": [_I],
     "lgen_attn_decode": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "lgen_rope_append_prefill": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "lgen_attn_prefill": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "lgen_sample": [_P, _P, _c.c_longlong, _P, _P, _P, _I, _I, _I, _I, _F, _I, _F, _I, _F, _I, _I, _P],
     "lgen_advance_state": [_P, _P],
     "lgen_vq_codebook_prep": [_P, _P, _P, _I, _I, _I, _P],

@@ -361,3 +361,168 @@ extern "C" int lgen_attn_decode(const void* q, const void* k_cache, const void* 
     LGEN_CHECK_LAUNCH();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Prefill of a conditioning prefix (t2i: T = cls_token_num caption tokens, gpt.py:348-349 / generate.py:77-86
+// with the emb_masks folded into causal_mask, generate.py:154-163): all T positions of all B2 rows go
+// through each layer at once (rows r = t * B2 + b of the packed activations) instead of T decode steps.
+//   lgen_rope_append_prefill : packed qkv rows -> RoPE(q, k) at position t (gpt.py:220-226, 420-430),
+//                              q rows [R][H][hdp], K/V appended at cache slot t of (b, h)
+//   lgen_attn_prefill        : masked causal attention of the prefix onto itself (gpt.py:229-236), fp32
+//                              math-SDPA semantics, output packed for the wo GEMM
+// T is small (120): plain VALU kernels, K/V of one (b, h) staged in LDS as fp32.
+// ---------------------------------------------------------------------------------------------
+template <typename D>
+__global__ __launch_bounds__(256) void rope_append_prefill_kernel(const uint4* __restrict__ qkvp, void* __restrict__ qrows,
+                                                                  void* __restrict__ kc, void* __restrict__ vc,
+                                                                  const float* __restrict__ freqs, int R, int B2, int MTs, int d,
+                                                                  int H, int hd, int hdp, int S8, int kvs, int pos0) {
+    constexpr int EPL = D::EPL;
+    const int KCH3 = 3 * d / D::KC;
+    const long long total = (long long)KCH3 * MTs * 64;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int lane = (int)(idx & 63);
+        const int mt = (int)((idx >> 6) % MTs);
+        const int kcx = (int)((idx >> 6) / MTs);
+        const int r = mt * 16 + (lane & 15);
+        if (r >= R) continue;
+        const int t = r / B2, b = r - t * B2;
+        float f[EPL];
+        D::unpack(qkvp[idx], f);
+        const int n0 = kcx * D::KC + (lane >> 4) * EPL;
+#pragma unroll
+        for (int e = 0; e < EPL; e += 2) {
+            const int n = n0 + e;
+            const int sec = n / d, c = n - sec * d;
+            const int head = c / hd, dd = c - head * hd;
+            float x0 = f[e], x1 = f[e + 1];
+            if (sec < 2) {  // interleaved (even, odd) pairs, fp32, one rounding at the store
+                const float2 cs = *(const float2*)(freqs + ((size_t)(pos0 + t) * (hd >> 1) + (dd >> 1)) * 2);
+                const float y0 = x0 * cs.x - x1 * cs.y, y1 = x1 * cs.x + x0 * cs.y;
+                x0 = y0; x1 = y1;
+            }
+            if (sec == 0) {
+                D::st(qrows, ((size_t)r * H + head) * hdp + dd, x0);
+                D::st(qrows, ((size_t)r * H + head) * hdp + dd + 1, x1);
+            } else {
+                void* cache = sec == 1 ? kc : vc;
+                const size_t o = (((size_t)b * H + head) * S8 + pos0 + t) * kvs + dd;
+                D::st(cache, o, x0);
+                D::st(cache, o + 1, x1);
+            }
+        }
+    }
+}
+
+extern "C" int lgen_rope_append_prefill(const void* qkv_packed, void* q_rows, void* k_cache, void* v_cache, const float* freqs,
+                                        int R, int B2, int MTs, int d, int n_head, int hd, int hdp, int S8, int kv_row_stride,
+                                        int pos0, int dtype, void* stream) {
+    const int kcsz = dtype == LGEN_BF16 ? 32 : 16;
+    if ((3 * d) % kcsz || d != n_head * hd || hd % 2 || R > MTs * 16 || B2 < 1 || R % B2) return LGEN_ERR_BAD_ARG;
+    const int kvs = kv_row_stride > 0 ? kv_row_stride : hdp;
+    const long long total = (long long)(3 * d / kcsz) * MTs * 64;
+    const int blocks = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == LGEN_BF16)
+        hipLaunchKernelGGL(rope_append_prefill_kernel<BF16>, dim3(blocks), dim3(256), 0, st, (const uint4*)qkv_packed, q_rows, k_cache,
+                           v_cache, freqs, R, B2, MTs, d, n_head, hd, hdp, S8, kvs, pos0);
+    else if (dtype == LGEN_F32)
+        hipLaunchKernelGGL(rope_append_prefill_kernel<F32>, dim3(blocks), dim3(256), 0, st, (const uint4*)qkv_packed, q_rows, k_cache,
+                           v_cache, freqs, R, B2, MTs, d, n_head, hd, hdp, S8, kvs, pos0);
+    else
+        return LGEN_ERR_BAD_ARG;
+    LGEN_CHECK_LAUNCH();
+    return 0;
+}
+
+#define PF_MAXT 128
+template <typename D>
+__global__ __launch_bounds__(256) void attn_prefill_kernel(const void* __restrict__ qrows, const void* __restrict__ kc,
+                                                           const void* __restrict__ vc, void* __restrict__ out,
+                                                           const unsigned char* __restrict__ mask, int T, int B2, int MTs, int H,
+                                                           int hd, int hdp, int S8, int kvs, float sf) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int ld = hd + 1;                       // padded row stride: lanes walk rows
+    float* Ks = sm;                              // [T][ld], pre-scaled by sf
+    float* Vs = Ks + (size_t)T * ld;             // [T][ld]
+    float* Ps = Vs + (size_t)T * ld;             // [4 waves][PF_MAXT]
+    float* Qs = Ps + 4 * PF_MAXT;                // [4 waves][hd], pre-scaled by sf
+    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int i = tid; i < T * hd; i += 256) {
+        const int s = i / hd, dd = i - s * hd;
+        const size_t o = (((size_t)b * H + h) * S8 + s) * kvs + dd;
+        Ks[s * ld + dd] = D::ld(kc, o) * sf;
+        Vs[s * ld + dd] = D::ld(vc, o);
+    }
+    __syncthreads();
+    for (int t = wv; t < T; t += 4) {
+        const int r = t * B2 + b;
+        for (int dd = lane; dd < hd; dd += 64) Qs[wv * hd + dd] = D::ld(qrows, ((size_t)r * H + h) * hdp + dd) * sf;
+        __builtin_amdgcn_wave_barrier();
+        const unsigned char* mrow = mask ? mask + ((size_t)b * S8 + t) * S8 : nullptr;
+        float sc[2];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int s = lane + u * 64;
+            float v = -INFINITY;
+            if (s < T && s <= t && (!mrow || mrow[s])) {
+                float dot = 0.f;
+                for (int dd = 0; dd < hd; ++dd) dot = fmaf(Qs[wv * hd + dd], Ks[s * ld + dd], dot);
+                v = dot;
+            }
+            sc[u] = v;
+            mx = fmaxf(mx, v);
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const float p = sc[u] > -INFINITY ? expf(sc[u] - mx) : 0.f;
+            sc[u] = p;
+            sum += p;
+        }
+        sum = wave_sum(sum);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (lane + u * 64 < PF_MAXT) Ps[wv * PF_MAXT + lane + u * 64] = sc[u] / sum;
+        __builtin_amdgcn_wave_barrier();
+        for (int dd = lane; dd < hd; dd += 64) {
+            float acc = 0.f;
+            for (int s = 0; s <= t; ++s) acc = fmaf(Ps[wv * PF_MAXT + s], Vs[s * ld + dd], acc);
+            D::st(out, D::xp_off(h * hd + dd, r >> 4, r & 15, MTs), acc);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+extern "C" int lgen_attn_prefill(const void* q_rows, const void* k_cache, const void* v_cache, void* out_packed,
+                                 const unsigned char* mask, int T, int B2, int MTs, int n_head, int hd, int hdp, int S8,
+                                 int kv_row_stride, int dtype, void* stream) {
+    if (T < 1 || T > PF_MAXT || T > S8 || B2 * T > MTs * 16) return LGEN_ERR_BAD_ARG;
+    const int kvs = kv_row_stride > 0 ? kv_row_stride : hdp;
+    const float sf = sqrtf(1.0f / sqrtf((float)hd));
+    const size_t lds = ((size_t)2 * T * (hd + 1) + 4 * PF_MAXT + 4 * hd) * sizeof(float);
+    if (lds > 160 * 1024) return LGEN_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == LGEN_BF16) {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void*)attn_prefill_kernel<BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+        }
+        hipLaunchKernelGGL(attn_prefill_kernel<BF16>, dim3(B2 * n_head), dim3(256), lds, st, q_rows, k_cache, v_cache, out_packed, mask,
+                           T, B2, MTs, n_head, hd, hdp, S8, kvs, sf);
+    } else if (dtype == LGEN_F32) {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void*)attn_prefill_kernel<F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+        }
+        hipLaunchKernelGGL(attn_prefill_kernel<F32>, dim3(B2 * n_head), dim3(256), lds, st, q_rows, k_cache, v_cache, out_packed, mask,
+                           T, B2, MTs, n_head, hd, hdp, S8, kvs, sf);
+    } else {
+        return LGEN_ERR_BAD_ARG;
+    }
+    LGEN_CHECK_LAUNCH();
+    return 0;
+}

@@ -348,6 +348,58 @@ class DecodeEngine:
         self.gemm(self.fc2, hid, out, B2 * T, mts, self.d, self.cap_hidden, L.EPI_ROWS, (mt, 1, 1))
         return out[: B2 * T].view(B2, T, self.d)
 
+    # ---- prefix prefill (t2i): all T caption positions through each layer at once -----------------------
+    def _prefill_prefix(self, emb: torch.Tensor):
+        """emb [B2, T, d] (CaptionEmbedder output) -> fills KV slots 0..T-1 of every layer and leaves the
+        residual stream of the LAST prefix position in the decode workspace (self.hp).  Same per-row math as
+        feeding the T positions one by one (rows are independent except through the masked attention), with
+        rows r = t * B2 + b of a [B2*T]-row packed activation set; stand-alone RMSNorm kernels (the fused
+        GEMMs are tuned for M <= 256)."""
+        lib, st, dt = self.lib, L.stream(), self.dt
+        B2, T, d = emb.shape
+        F, H, hd, hdp, S8 = self.F, self.H, self.hd, self.hdp, self.S8
+        R = B2 * T
+        mts = _ceil_div(R, 16)
+        mts = _ceil_div(mts, 8) * 8 if mts > 4 else (4 if mts == 3 else mts)
+        key = (R, mts)
+        ws = getattr(self, "_pf_ws", None)
+        if ws is None or ws["key"] != key:
+            z = lambda *s_: torch.zeros(*s_, dtype=self.dtype, device=self.dev)
+            ws = dict(key=key, hp=z(d // self.kc, mts, 64, self.epl), xn=z(d // self.kc, mts, 64, self.epl),
+                      ap=z(d // self.kc, mts, 64, self.epl), gp=z(F // self.kc, mts, 64, self.epl),
+                      qkv=z(3 * d // self.kc, mts, 64, self.epl), q=z(mts * 16, H, hdp))
+            self._pf_ws = ws
+        rows = emb.transpose(0, 1).reshape(R, d).to(self.dtype)  # r = t * B2 + b
+        ws["hp"].copy_(pack_act(rows.contiguous(), mts).view_as(ws["hp"]))
+        mt = min(mts, 4)
+        tile = lambda N, K: (mt, 1, max(1, min(8, (K // self.kc) // 2)))
+        pm = self.causal_mask if self.use_mask else None
+        for i, w in enumerate(self.layers):
+            L.check(lib.lgen_rmsnorm(L.ptr(ws["hp"]), L.ptr(w["an"]), L.ptr(ws["xn"]), mts, d, self.eps, dt, st), "rmsnorm")
+            self.gemm(w["wqkv"], ws["xn"], ws["qkv"], R, mts, 3 * d, d, L.EPI_PACKED, tile(3 * d, d))
+            L.check(lib.lgen_rope_append_prefill(L.ptr(ws["qkv"]), L.ptr(ws["q"]), L.ptr(self.k_cache[i]), L.ptr(self.v_cache[i]),
+                                                 L.ptr(self.freqs_cis), R, B2, mts, d, H, hd, hdp, S8, self.kvs, 0, dt, st),
+                    "rope_append_prefill")
+            L.check(lib.lgen_attn_prefill(L.ptr(ws["q"]), L.ptr(self.k_cache[i]), L.ptr(self.v_cache[i]), L.ptr(ws["ap"]), L.ptr(pm),
+                                          T, B2, mts, H, hd, hdp, S8, self.kvs, dt, st), "attn_prefill")
+            self.gemm(w["wo"], ws["ap"], ws["hp"], R, mts, d, d, L.EPI_RES, tile(d, d))
+            L.check(lib.lgen_rmsnorm(L.ptr(ws["hp"]), L.ptr(w["fn"]), L.ptr(ws["xn"]), mts, d, self.eps, dt, st), "rmsnorm")
+            self.gemm(w["w13"], ws["xn"], ws["gp"], R, mts, 2 * F, d, L.EPI_SWIGLU, (mt, 2, max(1, min(8, (d // self.kc) // 2))))
+            self.gemm(w["w2"], ws["gp"], ws["hp"], R, mts, d, F, L.EPI_RES, tile(d, F))
+        last = unpack_act(ws["hp"], R)[(T - 1) * B2:]
+        self._set_residual(last)
+
+    def _final_logits(self):
+        """norm + output on the decode workspace (gpt.py:367-368)."""
+        lib, st, dt, M, mts, d = self.lib, L.stream(), self.dt, self.B2, self.MTs, self.d
+        th = self._tiles("head", self.V, d)
+        if self.fuse_norm:
+            x_in, nw = self.hp, self.norm_w
+        else:
+            L.check(lib.lgen_rmsnorm(L.ptr(self.hp), L.ptr(self.norm_w), L.ptr(self.xnp), mts, d, self.eps, dt, st), "rmsnorm")
+            x_in, nw = self.xnp, None
+        self.gemm(self.out_w, x_in, self.logits, M, mts, self.V, d, L.EPI_ROWS, th, norm_w=nw)
+
     # ---- Exp(1) noise: what torch.multinomial draws, one [B, V] fp32 exponential_ per sampled token ----
     def _noise_begin(self, N, B, noise_seq):
         """noise[i] feeds the sampler of step i.  Injected (tests) or drawn from the device's default
@@ -396,10 +448,15 @@ class DecodeEngine:
             self._layers_and_logits()
         else:
             emb = self.caption_embed(cond_combined)
-            for t in range(T):  # causal prefix, one position at a time (same math as the batched prefill)
-                self.state[0] = t
-                self._set_residual(emb[:, t])
-                self._layers_and_logits(want_logits=(t == T - 1))
+            if os.environ.get("LGEN_SEQ_PREFILL") == "1" or T > 128:
+                for t in range(T):  # causal prefix, one position at a time through the decode kernels
+                    self.state[0] = t
+                    self._set_residual(emb[:, t])
+                    self._layers_and_logits(want_logits=(t == T - 1))
+            else:  # all T positions per layer at once
+                self._prefill_prefix(emb)
+                self.state[0] = T - 1
+                self._final_logits()
         self._sample(B, sp)
         yield 0
         # ---- decode (generate.py:105-123): every step first advances (pos, step)

@@ -147,8 +147,10 @@ __global__ __launch_bounds__(512) void gemm_normpre_kernel(GemmArgs a) {
 
 template <int MT, int NT, int EPI, int CPW>
 static int launch_np(const GemmArgs& a, int kw, hipStream_t st) {
-    // register budget: operands CPW * (MT + NT + 1) + accumulators + epilogue operands, <= ~220 at 8 waves
-    if constexpr ((CPW * (MT + NT + 1) + NT * MT * (epi_has_aux<EPI>() ? 2 : 1)) * 4 + 44 > 212) {
+    // shapes whose operand set does not fit 256 VGPRs (they spill; found by compiling everything once):
+    constexpr bool spills = (MT == 4 && CPW == 6) || (MT == 4 && NT >= 2 && EPI == EPI_QKV && CPW >= 5) ||
+                            (MT == 4 && NT == 4 && EPI == EPI_QKV) || (MT == 2 && NT == 4 && EPI == EPI_QKV && CPW == 6);
+    if constexpr (spills) {
         return LGEN_ERR_UNSUPPORTED;
     } else {
         dim3 grid((a.N / 16) / NT, a.MTs / MT);

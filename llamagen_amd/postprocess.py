@@ -48,3 +48,37 @@ def save_npz(samples_uint8: torch.Tensor, npz_path: str, num: Optional[int] = No
     assert arr.dtype == np.uint8 and arr.ndim == 4 and arr.shape[3] == 3, arr.shape
     np.savez(npz_path, arr_0=arr)
     return npz_path
+
+
+@torch.no_grad()
+def extract_codes(vq_model, x: torch.Tensor, ten_crop: bool = False) -> torch.Tensor:
+    """The per-batch body of autoregressive/train/extract_codes_c2i.py:92-103: augment (ten-crop input
+    [B, 10, 3, H, W], or horizontal flip of [B, 3, H, W]), VQModel.encode on the HIP path, ids reshaped to
+    [B, num_aug, h*w] int64 (on the device)."""
+    if ten_crop:
+        x_all, num_aug = x.flatten(0, 1), 10
+    else:
+        x_all, num_aug = torch.cat([x, torch.flip(x, dims=[-1])]), 2
+    _, _, (_, _, indices) = vq_model.encode(x_all)
+    if ten_crop:
+        return indices.reshape(x.shape[0], num_aug, -1)
+    # extract_codes_c2i.py:103 reshapes the [orig..., flipped...] batch as (B, num_aug, -1); with its batch size of 1
+    # that is (original, flipped) -- kept for B = 1 and made explicit (per image) for larger B
+    return indices.reshape(num_aug, x.shape[0], -1).transpose(0, 1).contiguous()
+
+
+def save_codes(codes: torch.Tensor, labels: torch.Tensor, code_path: str, dataset: str, image_size: int, index: int):
+    """On-disk code format of extract_codes_c2i.py:105-111, read back by dataset/imagenet.py:34-50:
+    `{code_path}/{dataset}{image_size}_codes/{index}.npy` int64 [1, num_aug, h*w] and
+    `{code_path}/{dataset}{image_size}_labels/{index}.npy` int64 [1]."""
+    import os
+    cdir = os.path.join(code_path, f"{dataset}{image_size}_codes")
+    ldir = os.path.join(code_path, f"{dataset}{image_size}_labels")
+    os.makedirs(cdir, exist_ok=True)
+    os.makedirs(ldir, exist_ok=True)
+    c = codes.detach().cpu().numpy().astype(np.int64)
+    y = labels.detach().cpu().numpy().astype(np.int64)
+    assert c.ndim == 3 and c.shape[0] == 1 and y.shape == (1,), (c.shape, y.shape)
+    np.save(os.path.join(cdir, f"{index}.npy"), c)
+    np.save(os.path.join(ldir, f"{index}.npy"), y)
+    return os.path.join(cdir, f"{index}.npy"), os.path.join(ldir, f"{index}.npy")

@@ -87,3 +87,14 @@ def test_save_npz_layout(tmp_path):
     p = save_npz(torch.from_numpy(arr), str(tmp_path / "s.npz"))
     z = np.load(p)
     assert list(z.keys()) == ["arr_0"] and np.array_equal(z["arr_0"], arr)
+
+
+def test_save_codes_format(tmp_path):
+    """extract_codes_c2i.py:105-111 file layout, as dataset/imagenet.py:34-50 reads it back."""
+    import numpy as np
+    from llamagen_amd.postprocess import save_codes
+    codes = torch.arange(2 * 9).reshape(1, 2, 9)
+    cp, lp = save_codes(codes, torch.tensor([7]), str(tmp_path), "imagenet", 48, 5)
+    assert cp.endswith("imagenet48_codes/5.npy") and lp.endswith("imagenet48_labels/5.npy")
+    f, y = np.load(cp), np.load(lp)
+    assert f.dtype == np.int64 and f.shape == (1, 2, 9) and np.array_equal(f[:, 1], codes.numpy()[:, 1]) and y.tolist() == [7]

@@ -239,3 +239,19 @@ def test_postprocess_uint8_matches_reference_golden():
     gold = load_golden("vq_vq16_4x4")
     img = torch.from_numpy(gold["image"]).to(_dev())
     assert np.array_equal(to_uint8_hwc(img).cpu().numpy(), gold["uint8"])
+
+
+def test_extract_codes_flip_augmentation():
+    """extract_codes_c2i.py:92-103 on the HIP encoder: ids of the image and of its horizontal flip, [B, 2, h*w]."""
+    from llamagen_amd.postprocess import extract_codes
+    case = VQ_CASES["enc16_32x32"]
+    m, sd = build_vq_holder(case)
+    dev = _dev()
+    m = m.to(dev)
+    x = make_vq_inputs(case)["x"].to(dev)
+    codes = extract_codes(m, x)
+    assert tuple(codes.shape) == (2, 2, 4) and codes.dtype == torch.int64
+    gold = load_golden("vq_enc16_32x32")
+    np.testing.assert_array_equal(codes[:, 0].reshape(-1).cpu().numpy(), gold["indices"])
+    _, idx_f, _ = O.vq_encode(sd, torch.flip(x.cpu(), dims=[-1]))
+    np.testing.assert_array_equal(codes[:, 1].reshape(-1).cpu().numpy(), idx_f.numpy())

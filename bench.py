@@ -214,6 +214,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # transparency: the same workload with ONE batch in flight (2 steps on lane 0), outside the timed region above
+    lane1 = None
+    if args.lanes > 1:
+        one = SamplingPipeline.__new__(SamplingPipeline)
+        one.dev, one.lanes, one.steps_per_turn = pipe.dev, pipe.lanes[:1], pipe.steps_per_turn
+        fence()
+        t1 = time.perf_counter()
+        one.run([torch.randint(0, 1000, (BATCH,), device=dev) for _ in range(2)], N, **skw)
+        fence()
+        lane1 = BATCH * world * 2 / (time.perf_counter() - t1)
+
     if rank == 0:
         out = outs[-1]
         assert out is not None and out.shape[0] == BATCH * world and torch.isfinite(out).all()
@@ -225,7 +236,8 @@ def main():
                                       "bf16) + VQ-16 decode_code (fp32-class), batch 32 per step per GPU, random-init "
                                       f"weights; {args.lanes} steps in flight per GPU on separate HIP streams",
                           "global_batch": BATCH * world, "tokens_per_image": N, "parallelism": f"dp{world}",
-                          "steps_in_flight_per_gpu": args.lanes}}
+                          "steps_in_flight_per_gpu": args.lanes,
+                          "images_per_s_with_one_step_in_flight": None if lane1 is None else round(lane1, 3)}}
         if not args.no_roofline:
             sec, launches, per_pos = measure_attention(pipe.lanes[0].gpt, 2 * BATCH, N)
             nbytes, nl = attention_bytes_per_generate(gpt.config, 2 * BATCH, N)

@@ -165,6 +165,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--lanes", type=int, default=0, help="batches in flight per GPU (llamagen_amd/pipeline.py); "
                                                          "0 = pick 1..3 from the step count")
+    ap.add_argument("--steps-per-turn", type=int, default=1, help="decode steps a lane enqueues per scheduler turn")
+    ap.add_argument("--vq-own-stream", action="store_true", help="decode images on a separate shared stream (measured slower)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -188,7 +190,7 @@ def main():
         # lanes costs floor(K/L) * T_L + T_(K mod L): use the cheapest L
         T = {0: 0.0, 1: 1.0, 2: 1.44, 3: 2.02}
         args.lanes = min((1, 2, 3), key=lambda l: (args.steps // l) * T[l] + T[args.steps % l])
-    pipe = SamplingPipeline(gpt, vq, lanes=args.lanes)
+    pipe = SamplingPipeline(gpt, vq, lanes=args.lanes, steps_per_turn=args.steps_per_turn, vq_low_priority=args.vq_own_stream)
     pipe.prepare(BATCH, N, **skw)  # setup (like loading weights): KV slabs, workspaces, decode graphs per lane
     torch.cuda.synchronize()
 
@@ -218,7 +220,7 @@ def main():
     lane1 = None
     if args.lanes > 1:
         one = SamplingPipeline.__new__(SamplingPipeline)
-        one.dev, one.lanes, one.steps_per_turn = pipe.dev, pipe.lanes[:1], pipe.steps_per_turn
+        one.dev, one.lanes, one.steps_per_turn, one.vq_stream = pipe.dev, pipe.lanes[:1], pipe.steps_per_turn, pipe.vq_stream
         fence()
         t1 = time.perf_counter()
         one.run([torch.randint(0, 1000, (BATCH,), device=dev) for _ in range(2)], N, **skw)

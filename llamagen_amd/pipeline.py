@@ -25,11 +25,18 @@ from .generate import generate_iter
 
 
 class SamplingLane:
-    def __init__(self, gpt, vq=None, stream: Optional[torch.cuda.Stream] = None, primary: bool = False):
+    """One in-flight batch: generate() and decode_code() on the lane's stream.  `vq_stream` (optional) moves the
+    VQ decoder to a separate (shared, lower-priority) stream so that the lane can start its next batch at once --
+    measured WORSE on MI355X (50 vs 65 img/s with 3 lanes: a 4th active stream drops the dispatch rate, see
+    tools/ubench_cp.py), so the default keeps the decoder on the lane's stream."""
+
+    def __init__(self, gpt, vq=None, stream: Optional[torch.cuda.Stream] = None, primary: bool = False,
+                 vq_stream: Optional[torch.cuda.Stream] = None):
         self.gpt = gpt if primary else gpt.lane_view()
         self.vq = vq
         self.dev = next(gpt.parameters()).device
         self.stream = stream or torch.cuda.Stream(device=self.dev)
+        self.vq_stream = vq_stream or self.stream
         self._it = None
         self._job = None
 
@@ -55,9 +62,12 @@ class SamplingLane:
                 return None
             except StopIteration as stop:
                 idx = stop.value
-            job_id, B, N, shape = self._job
-            img = None
-            if self.vq is not None:
+        job_id, B, N, shape = self._job
+        img = None
+        if self.vq is not None:
+            self.vq_stream.wait_stream(self.stream)
+            idx.record_stream(self.vq_stream)
+            with torch.cuda.stream(self.vq_stream), torch.no_grad():
                 lat = int(round(N ** 0.5))
                 img = self.vq.decode_code(idx, shape or [B, 8, lat, lat])
         self._it = None
@@ -72,9 +82,12 @@ class SamplingPipeline:
     """Keeps up to `lanes` batches in flight.  run(conds) -> [(ids, images)] in submission order; the
     results are enqueued-behind on the CURRENT stream when run() returns (no host synchronisation)."""
 
-    def __init__(self, gpt, vq=None, lanes: int = 2, steps_per_turn: int = 1):
+    def __init__(self, gpt, vq=None, lanes: int = 2, steps_per_turn: int = 1, vq_low_priority: bool = False):
         self.dev = next(gpt.parameters()).device
-        self.lanes: List[SamplingLane] = [SamplingLane(gpt, vq, primary=(i == 0)) for i in range(max(1, lanes))]
+        # optional: one shared stream for every lane's VQ decode (see SamplingLane)
+        self.vq_stream = torch.cuda.Stream(device=self.dev, priority=0) if (vq is not None and vq_low_priority) else None
+        self.lanes: List[SamplingLane] = [SamplingLane(gpt, vq, primary=(i == 0), vq_stream=self.vq_stream)
+                                          for i in range(max(1, lanes))]
         self.steps_per_turn = steps_per_turn
 
     def prepare(self, batch: int, max_new_tokens: int, **gen_kw):
@@ -111,4 +124,6 @@ class SamplingPipeline:
         cur = torch.cuda.current_stream(self.dev)
         for lane in self.lanes:
             cur.wait_stream(lane.stream)
+        if self.vq_stream is not None:
+            cur.wait_stream(self.vq_stream)
         return results

@@ -327,7 +327,7 @@ __global__ __launch_bounds__(64 * ATT_NW, (ATT_CH <= 2 ? 4 : 2)) void attn_decod
 
 // variant (ATT_CH K/V loads per buffer, waves per (b, h) workgroup): 2 = default (2, 2): 128-thread workgroups,
 // every workgroup of a B2 x H = 1024 grid resident at once, lowest fixed cost (4.4 us at kv_len 1 vs 6.1 us with
-// 4 waves) and the same 6.4 TB/s incremental rate at long kv_len; 1 = (2, 4); 0 = (4, 4); 3 = (4, 2)
+// 4 waves) and the same 6.4 TB/s incremental rate at long kv_len; 1 = (2, 4); 0 = (4, 4); 3 = (4, 2); 4 = (2, 1); 5 = (4, 1)
 static int g_attn_variant = 2;
 extern "C" int lgen_set_attn_variant(int v) { g_attn_variant = v; return 0; }
 
@@ -343,13 +343,15 @@ extern "C" int lgen_attn_decode(const void* q, const void* k_cache, const void* 
     if (dtype != LGEN_BF16 && dtype != LGEN_F32) return LGEN_ERR_BAD_ARG;
     if (hdp % epl || hd > hdp || B2 > MTs * 16 || S8 < 1 || a.kvs < hdp || a.kvs % epl) return LGEN_ERR_BAD_ARG;
     const int lpk = hdp / epl;
-    const int nw = g_attn_variant >= 2 ? 2 : 4;
+    const int nw = g_attn_variant >= 4 ? 1 : (g_attn_variant >= 2 ? 2 : 4);
     dim3 grid(B2 * n_head), block(64 * nw);
 #define LGEN_ATT(DT, L)                                                                              \
     do {                                                                                             \
         if (g_attn_variant == 1) hipLaunchKernelGGL((attn_decode_kernel<DT, L, 2, 4>), grid, block, 0, st, a);      \
         else if (g_attn_variant == 2) hipLaunchKernelGGL((attn_decode_kernel<DT, L, 2, 2>), grid, block, 0, st, a); \
         else if (g_attn_variant == 3) hipLaunchKernelGGL((attn_decode_kernel<DT, L, 4, 2>), grid, block, 0, st, a); \
+        else if (g_attn_variant == 4) hipLaunchKernelGGL((attn_decode_kernel<DT, L, 2, 1>), grid, block, 0, st, a); \
+        else if (g_attn_variant == 5) hipLaunchKernelGGL((attn_decode_kernel<DT, L, 4, 1>), grid, block, 0, st, a); \
         else hipLaunchKernelGGL((attn_decode_kernel<DT, L, 4, 4>), grid, block, 0, st, a);                          \
     } while (0)
     if (dtype == LGEN_BF16 && lpk == 8) LGEN_ATT(BF16, 8);

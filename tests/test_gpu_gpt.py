@@ -240,7 +240,7 @@ def test_qkv_rope_append_and_attention(dt, B2, H, hd, grid, pos, interleave):
     vc_d[..., :hd] = vref.to(dt).to(dev)
     q_d[:B2, :, :hd] = xq[:, 0].to(dt).to(dev)
     kcd = 32 if dt == torch.bfloat16 else 16
-    for use_mask, variant in ((False, 0), (True, 0), (False, 1), (True, 1), (False, 2), (True, 3)):
+    for use_mask, variant in ((False, 0), (True, 0), (False, 1), (True, 1), (False, 2), (True, 3), (True, 4), (False, 5)):
         L.lib().lgen_set_attn_variant(variant)
         mask = torch.tril(torch.ones(S8, S8, dtype=torch.bool)).unsqueeze(0).repeat(B2, 1, 1)
         if use_mask:

@@ -90,7 +90,7 @@ def main(name="GPT-L", B=32, img=384):
     for tl in [(4, 2, 8), (4, 4, 8), (4, 4, 4)]:
         report(f"head {tl} norm=True", lambda: [e.gemm(e.out_w, e.hp, e.logits, M, mts, V, d, L.EPI_ROWS, tl, norm_w=e.norm_w) for _ in range(8)], 8, V * d * 2)
     report("rmsnorm standalone", lambda: [L.check(lib.lgen_rmsnorm(L.ptr(e.hp), L.ptr(e.norm_w), L.ptr(e.xnp), mts, d, e.eps, dt, st()), "n") for _ in range(48)], 48)
-    for variant in (1, 2, 3):
+    for variant in (2, 4, 5):
         lib.lgen_set_attn_variant(variant)
         for pos in (0, 64, 144, 288, 575):
             e.state.copy_(torch.tensor([pos, pos], dtype=torch.int32, device=dev))

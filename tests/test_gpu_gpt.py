@@ -512,3 +512,30 @@ def test_t2i_batched_prefill_matches_sequential(dt, monkeypatch):
     assert (v_seq - v_bat).abs().max().item() <= tol * max(1.0, v_seq.abs().max().item())
     if dt == torch.float32:
         assert torch.equal(t_seq, t_bat)
+
+
+def test_full_size_config2_properties(monkeypatch):
+    """BASELINE config 2 at full size (GPT-L, 384 px, 32 images, cfg 4.0, top-k 2000, bf16) through size-independent
+    properties: ids in range and well spread, same seed -> same ids, hipGraph replay == eager launches, fused-norm
+    GEMMs in use, and a second call (KV slabs not re-zeroed) is unaffected by the first."""
+    from llamagen_amd import GPT_models, generate
+    dev = _dev()
+    torch.manual_seed(0)
+    m = GPT_models["GPT-L"](vocab_size=16384, block_size=576, num_classes=1000, cls_token_num=1, model_type="c2i")
+    torch.nn.init.normal_(m.output.weight, 0, 0.02)
+    m = m.to(device=dev, dtype=torch.bfloat16).eval()
+    c = torch.randint(0, 1000, (32,), generator=torch.Generator().manual_seed(1)).to(dev)
+    kw = dict(cfg_scale=4.0, cfg_interval=-1, temperature=1.0, top_k=2000, top_p=1.0, sample_logits=True)
+    torch.manual_seed(123)
+    other = generate(m, torch.flip(c, dims=[0]), 576, **kw)  # dirties the KV slabs with a different batch
+    torch.manual_seed(7)
+    a = generate(m, c, 576, **kw)
+    assert m._engine.fuse_norm and a.dtype == torch.int32 and tuple(a.shape) == (32, 576)
+    assert int(a.min()) >= 0 and int(a.max()) < 16384 and a.unique().numel() > 4000
+    torch.manual_seed(7)
+    b = generate(m, c, 576, **kw)
+    assert torch.equal(a, b) and not torch.equal(a, other)
+    monkeypatch.setenv("LGEN_NO_GRAPH", "1")
+    torch.manual_seed(7)
+    e = generate(m, c, 576, **kw)
+    assert torch.equal(a, e)

@@ -46,10 +46,11 @@ def main(name="GPT-L", B=32, img=384):
     from llamagen_amd import _lib as L
     tilesets = {
         "default": {},
-        "half-WG": {"qkv": (2, 4, 8), "w13": (4, 4, 8), "wo": (2, 1, 8), "w2": (2, 1, 16)},
-        "quarter-WG": {"qkv": (4, 4, 8), "w13": (4, 4, 8), "wo": (4, 1, 8), "w2": (4, 1, 8)},
+        "lean qkv(1,2) w13(1,2)": {"qkv": (1, 2, 8), "w13": (1, 2, 8)},
+        "lean qkv(1,2) w13(2,2)": {"qkv": (1, 2, 8), "w13": (2, 2, 8)},
+        "lean qkv(1,2)": {"qkv": (1, 2, 8)},
     }
-    for G in (1, 2, 3):
+    for G in (3,):
         streams = [torch.cuda.Stream() for _ in range(G)]
         engs = [build(name, B, N, dev, s) for s in streams]
         for tname, tiles in tilesets.items():
@@ -72,7 +73,7 @@ def main(name="GPT-L", B=32, img=384):
                     best = min(best, (time.perf_counter() - t0) / 20 * 1e6)
                 res.append(f"pos {pos}: {best / G:7.1f} us/batch-step")
                 del gs
-            print(f"{G} concurrent batches, tiles {tname:10s}: " + "   ".join(res), flush=True)
+            print(f"{G} concurrent batches, tiles {tname:24s}: " + "   ".join(res), flush=True)
         del engs
 
 

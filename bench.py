@@ -254,6 +254,23 @@ def main():
                                "avg_launch_us": round(sec / launches * 1e6, 2),
                                "algorithmic_bytes_per_launch": int(nbytes / launches),
                                "launch_us_by_position": per_pos}
+        if not args.no_roofline:
+            # second hot kernel family (MFMA-bound): the VQ decoder's implicit-GEMM convolutions.  570.1 GFLOP per
+            # 384 px image x 3 split-bf16 MFMA passes, timed live over whole decode_code()
+            # calls (so GroupNorm / gather time counts against it) on the current stream.
+            codes = torch.randint(0, 16384, (BATCH, N), device=dev)
+            vq.decode_code(codes, [BATCH, 8, LAT, LAT])
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                vq.decode_code(codes, [BATCH, 8, LAT, LAT])
+            e1.record()
+            torch.cuda.synchronize()
+            vq_ms = e0.elapsed_time(e1) / 3
+            tf = 3 * 570.1e9 * BATCH / (vq_ms * 1e-3) / 1e12
+            res["roofline_vq_decode"] = {"bound": "mfma", "kernel": "igemm_kernel (+ GroupNorm/split passes)", "achieved": round(tf, 1),
+                                         "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
+                                         "ms_per_decode_code": round(vq_ms, 2), "flop_per_image_fp32": 570.1e9, "mfma_passes": 3}
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)

@@ -13,10 +13,11 @@
 //
 // Tiling: workgroup = 4 waves, BM = WMW*JM*16 pixels x BN = WNW*JN*16 output channels, K-step =
 // one tap x 32 input channels.  The pixel tile is 128 consecutive NHWC pixels of one image; the
-// nine taps re-read shifted rows through L2.  Global -> registers -> LDS double buffer with TWO
-// register staging sets (loads for step s+2 are issued before the MFMAs of step s and written to
-// LDS after the MFMAs of step s+1; one barrier per step; measured: 70 % of wave cycles were spent
-// waiting on memory with a one-step prefetch distance).  LDS
+// nine taps re-read shifted rows through L2.  Global -> registers -> LDS double buffer; the PIXEL tile has
+// two register staging sets (its loads for step s+2 are issued before the MFMAs of step s and written to
+// LDS after the MFMAs of step s+1), the L2-hot weight tile one (a second full set spills at 128x128); one
+// barrier per step.  All staging loads are unconditional (border lanes are zeroed at the LDS write):
+// with per-lane conditional loads 70 % of the wave cycles were spent waiting, 37 % without.  LDS
 // tiles are [rows][32] bf16 with a 16-byte-slot XOR swizzle that makes both the staging
 // `ds_write_b128` and the fragment `ds_read_b128` conflict-free for the 16x16x32 operand layout.
 // The weight tile is the MFMA A operand and the pixel tile the B operand, so a lane ends up with
@@ -38,7 +39,7 @@ struct IgemmArgs {
 
 LGEN_DEV int swz(int row, int seg) { return row * 64 + ((seg ^ ((row >> 2) & 2)) << 4); }  // byte offset in a [rows][32]bf16 tile
 
-template <int JN, int JM, int WNW, bool DS>
+template <int JN, int JM, int WNW, int DS>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
     constexpr int WMW = 4 / WNW;
     constexpr int BM = WMW * JM * 16, BN = WNW * JN * 16;
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
     // vmcnt per element.
     uint4 s0_ah[A_IT], s0_al[A_IT], s0_bh[B_IT], s0_bl[B_IT], s1_ah[A_IT], s1_al[A_IT], s1_bh[B_IT], s1_bl[B_IT];
     bool s0_ok[A_IT], s1_ok[A_IT];
-#define IG_GLOAD(step_, P)                                                                              \
+#define IG_GLOAD_A(step_, P)                                                                            \
     {                                                                                                   \
         const int st_ = (step_) < nsteps ? (step_) : nsteps - 1; /* tail: harmless re-load */           \
         const int tap = st_ / kchunks, kc = st_ - tap * kchunks;                                        \
@@ -97,6 +98,11 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
             P##ah[i] = *(const uint4*)(ahi + off);                                                      \
             P##al[i] = *(const uint4*)(alo + off);                                                      \
         }                                                                                               \
+    }
+#define IG_GLOAD_B(step_, P)                                                                            \
+    {                                                                                                   \
+        const int st_ = (step_) < nsteps ? (step_) : nsteps - 1;                                        \
+        const int tap = st_ / kchunks, kc = st_ - tap * kchunks;                                        \
         _Pragma("unroll") for (int i = 0; i < B_IT; ++i) {                                              \
             const int idx = t + i * 256;                                                                \
             const int row = idx < BN * 4 ? (idx >> 2) : 0;                                              \
@@ -105,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
             P##bl[i] = *(const uint4*)(wlo + off);                                                      \
         }                                                                                               \
     }
-#define IG_LSTORE(buf_, P)                                                                              \
+#define IG_LSTORE_A(buf_, P)                                                                            \
     {                                                                                                   \
         unsigned char* base = smem + (buf_) * STAGE;                                                    \
         _Pragma("unroll") for (int i = 0; i < A_IT; ++i) {                                              \
@@ -117,6 +123,10 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
                 *(uint4*)(base + BM * 64 + o) = make_uint4(P##al[i].x & m_, P##al[i].y & m_, P##al[i].z & m_, P##al[i].w & m_); \
             }                                                                                           \
         }                                                                                               \
+    }
+#define IG_LSTORE_B(buf_, P)                                                                            \
+    {                                                                                                   \
+        unsigned char* base = smem + (buf_) * STAGE;                                                    \
         _Pragma("unroll") for (int i = 0; i < B_IT; ++i) {                                              \
             const int idx = t + i * 256;                                                                \
             if (B_FULL || idx < BN * 4) {                                                               \
@@ -157,31 +167,63 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
         }
     };
 
-    IG_GLOAD(0, s0_);
-    if constexpr (DS) IG_GLOAD(1, s1_);
-    IG_LSTORE(0, s0_);
-    __syncthreads();
-    if constexpr (!DS) {  // one staging set: loads of step s+1 fly during the MFMAs of step s only
+#define IG_GLOAD(step_, P) { IG_GLOAD_A(step_, P); IG_GLOAD_B(step_, P); }
+#define IG_LSTORE(buf_, P) { IG_LSTORE_A(buf_, P); IG_LSTORE_B(buf_, P); }
+    if constexpr (DS == 0) {  // one staging set: loads of step s+1 fly during the MFMAs of step s only
+        IG_GLOAD(0, s0_);
+        IG_LSTORE(0, s0_);
+        __syncthreads();
         for (int step = 0; step < nsteps; ++step) {
             IG_GLOAD(step + 1, s0_);
             compute(step & 1);
             IG_LSTORE((step & 1) ^ 1, s0_);
             __syncthreads();
         }
-    } else
-    for (int step = 0; step < nsteps; step += 2) {
-        IG_GLOAD(step + 2, s0_);   // set 0 (step) is already in LDS buffer 0
-        compute(0);
-        IG_LSTORE(1, s1_);         // step + 1, requested one iteration ago
+    } else if constexpr (DS == 1) {  // two full staging sets (spills at the 128x128 tile)
+        IG_GLOAD(0, s0_);
+        IG_GLOAD(1, s1_);
+        IG_LSTORE(0, s0_);
         __syncthreads();
-        if (step + 1 >= nsteps) break;
-        IG_GLOAD(step + 3, s1_);
-        compute(1);
-        IG_LSTORE(0, s0_);         // step + 2
+        for (int step = 0; step < nsteps; step += 2) {
+            IG_GLOAD(step + 2, s0_);   // set 0 (step) is already in LDS buffer 0
+            compute(0);
+            IG_LSTORE(1, s1_);         // step + 1, requested one iteration ago
+            __syncthreads();
+            if (step + 1 >= nsteps) break;
+            IG_GLOAD(step + 3, s1_);
+            compute(1);
+            IG_LSTORE(0, s0_);         // step + 2
+            __syncthreads();
+        }
+    } else {  // DS == 2: two sets for the pixel tile (HBM/L2 latency), one for the (L2-hot) weight tile
+        IG_GLOAD_A(0, s0_);
+        IG_GLOAD_B(0, s0_);
+        IG_GLOAD_A(1, s1_);
+        IG_LSTORE_A(0, s0_);
+        IG_LSTORE_B(0, s0_);
         __syncthreads();
+        for (int step = 0; step < nsteps; step += 2) {
+            IG_GLOAD_A(step + 2, s0_);
+            IG_GLOAD_B(step + 1, s0_);
+            compute(0);
+            IG_LSTORE_A(1, s1_);
+            IG_LSTORE_B(1, s0_);
+            __syncthreads();
+            if (step + 1 >= nsteps) break;
+            IG_GLOAD_A(step + 3, s1_);
+            IG_GLOAD_B(step + 2, s0_);
+            compute(1);
+            IG_LSTORE_A(0, s0_);
+            IG_LSTORE_B(0, s0_);
+            __syncthreads();
+        }
     }
 #undef IG_GLOAD
 #undef IG_LSTORE
+#undef IG_GLOAD_A
+#undef IG_GLOAD_B
+#undef IG_LSTORE_A
+#undef IG_LSTORE_B
 
     // epilogue: lane holds out channels n = nb + fg*4 + {0..3} of pixel p = pb + fr
     float* outb = a.out + (size_t)b * a.o_bstride;
@@ -218,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
     }
 }
 
-template <int JN, int JM, int WNW, bool DS>
+template <int JN, int JM, int WNW, int DS>
 static int launch_igemm(const IgemmArgs& a, int B, hipStream_t st) {
     constexpr int BM = (4 / WNW) * JM * 16, BN = WNW * JN * 16;
     const size_t lds = 2 * (size_t)(BM + BN) * 64 * 2;
@@ -235,8 +277,9 @@ static int launch_igemm(const IgemmArgs& a, int B, hipStream_t st) {
     return 0;
 }
 
-// tuning knob (tools/): 0 = 128x128 tile, one staging set; 1 = 128x128, two staging sets; 2 = 128x64 tiles, two sets
-static int g_igemm_variant = 0;
+// tuning knob (tools/): 0 = 128x128 tile, one staging set; 1 = 128x128, two staging sets; 2 = 128x64 tiles, two sets;
+// 3 = 128x128, two sets for the pixel tile only
+static int g_igemm_variant = 3;
 extern "C" int lgen_set_igemm_variant(int v) { g_igemm_variant = v; return 0; }
 
 extern "C" int lgen_conv_igemm(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo, const float* bias,
@@ -254,9 +297,12 @@ extern "C" int lgen_conv_igemm(const void* a_hi, const void* a_lo, const void* w
                             : (long long)(H >> (upsample ? 1 : 0)) * (W >> (upsample ? 1 : 0)) * Cin,
                 w_bstride, (long long)H * W * Cout, alpha};
     hipStream_t st = (hipStream_t)stream;
-    if (g_igemm_variant == 2 && Npad % 64 == 0) return launch_igemm<4, 2, 1, true>(a, B, st);
-    if (Npad % 128 == 0)                                            // 128 px x 128 ch
-        return g_igemm_variant == 1 ? launch_igemm<4, 4, 2, true>(a, B, st) : launch_igemm<4, 4, 2, false>(a, B, st);
-    if (Npad % 64 == 0) return launch_igemm<4, 2, 1, true>(a, B, st);    // 128 px x 64 ch
-    return launch_igemm<1, 2, 1, true>(a, B, st);                        // 128 px x 16 ch (conv_out, Cout = 3)
+    if (g_igemm_variant == 2 && Npad % 64 == 0) return launch_igemm<4, 2, 1, 1>(a, B, st);
+    if (Npad % 128 == 0) {                                          // 128 px x 128 ch
+        if (g_igemm_variant == 1) return launch_igemm<4, 4, 2, 1>(a, B, st);
+        if (g_igemm_variant == 3) return launch_igemm<4, 4, 2, 2>(a, B, st);
+        return launch_igemm<4, 4, 2, 0>(a, B, st);
+    }
+    if (Npad % 64 == 0) return launch_igemm<4, 2, 1, 1>(a, B, st);    // 128 px x 64 ch
+    return launch_igemm<1, 2, 1, 1>(a, B, st);                        // 128 px x 16 ch (conv_out, Cout = 3)
 }

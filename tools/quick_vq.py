@@ -10,7 +10,7 @@ def main(B=32, lat=24):
     vq = VQ_models["VQ-16"](codebook_size=16384, codebook_embed_dim=8).to(dev).eval()
     codes = torch.randint(0, 16384, (B, lat * lat), device=dev)
     from llamagen_amd import _lib as L
-    for variant in (0, 1, 2):
+    for variant in (3, 0):
       L.lib().lgen_set_igemm_variant(variant)
       print("igemm variant", variant)
       for r in range(3):

@@ -173,6 +173,8 @@ int lgen_prefetch_hint(const void* next_weights, long long bytes);
 
 /* ---- tuning knobs (process-wide kernel variant selection; defaults are the measured-best ones) ---- */
 int lgen_set_attn_variant(int v);  /* (K/V loads per buffer, waves per (b,h)): 2 (default) = (2,2); 1 = (2,4); 0 = (4,4); 3 = (4,2); 4 = (2,1); 5 = (4,1) */
+int lgen_set_weight_nt(int v);     /* 0 (default): GEMM weight loads with the default cache policy; 1: non-temporal */
+int lgen_set_kv_nt(int v);         /* decode attention K/V loads: 1 (default) non-temporal, 0 default cache policy */
 int lgen_set_igemm_variant(int v); /* 3 (default): 128x128 tile, 2 staging sets for pixels / 1 for weights; 0: 1 set; 1: 2 full sets; 2: 128x64 tiles */
 
 #ifdef __cplusplus

@@ -37,6 +37,8 @@ SIGNATURES = {
     "lgen_prefetch_hint": [_P, _c.c_longlong],
     "lgen_set_attn_variant": [_I],
     "lgen_set_igemm_variant": [_I],
+    "lgen_set_weight_nt": [_I],
+    "lgen_set_kv_nt": [_I],
     "lgen_attn_decode": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "lgen_rope_append_prefill": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "lgen_attn_prefill": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],

@@ -24,7 +24,11 @@ struct GemmArgs {
     float eps, inv_k;
     const char* pf;      // weights of the NEXT kernel of the chain (nullable): pulled towards the memory-side cache
     long long pf_bytes;
+    int nt;              // weight loads non-temporal (streamed once) or default cache policy (shared between lanes)
 };
+// weight chunk load with the policy of this launch (uniform branch)
+LGEN_DEV uint4 ldg_w(const uint4* p, int nt) { return nt ? ldg_nt(p) : *p; }
+int lgen_weight_nt();  // gemm_skinny.hip
 
 // Fire-and-forget reads of the next kernel's weight matrix, one dword per 64-byte line, issued BEFORE this
 // wave's own operand loads.  Each kernel of the decode chain is latency-bound and starts with a cold weight

@@ -19,7 +19,8 @@
 // no LDS staging, no barriers in the main loop.  A workgroup owns NT 16-row tiles of N for all
 // M rows; its KW waves split K between them, each keeps DEPTH k-chunks of loads in flight
 // (register ring, static indices) and they combine through LDS in a fixed order (deterministic,
-// no atomics).  Weights are loaded non-temporally (read once per step).  Everything an epilogue
+// no atomics).  Weight loads use the default cache policy (lanes a few layers apart share the stream in the
+// memory-side cache; non-temporal is a knob, lgen_set_weight_nt).  Everything an epilogue
 // needs from memory (residual tile, RoPE angles) is requested before the main loop.
 #include "lgen_common.h"
 #include "../../include/lgen.h"

@@ -39,6 +39,7 @@ SIGNATURES = {
     "lgen_set_igemm_variant": [_I],
     "lgen_set_weight_nt": [_I],
     "lgen_set_kv_nt": [_I],
+    "lgen_set_vq_nt": [_I],
     "lgen_attn_decode": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "lgen_rope_append_prefill": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "lgen_attn_prefill": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],

@@ -32,6 +32,7 @@ struct IgemmArgs {
     const float* res;    // like out (NHWC) or null
     float* out;
     int H, W, Cin, Cout, Npad, ks, ups, out_nchw;
+    int nt;      // streaming (non-temporal) output stores: the fp32 result is far larger than any cache
     int stride;  // 1, or 2 = Downsample (vq_model.py:389-393): input (2H) x (2W), zero pad right/bottom only
     long long a_bstride, w_bstride, o_bstride;
     float alpha;
@@ -247,7 +248,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
                     const float4 r = *(const float4*)(resb + o);
                     v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
                 }
-                *(float4*)(outb + o) = make_float4(v[0], v[1], v[2], v[3]);
+                if (a.nt) stg_nt_f4((float4*)(outb + o), v[0], v[1], v[2], v[3]);
+                else *(float4*)(outb + o) = make_float4(v[0], v[1], v[2], v[3]);
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -277,6 +279,7 @@ static int launch_igemm(const IgemmArgs& a, int B, hipStream_t st) {
     return 0;
 }
 
+int lgen_vq_nt();  // vq_ops.hip
 // tuning knob (tools/): 0 = 128x128 tile, one staging set; 1 = 128x128, two staging sets; 2 = 128x64 tiles, two sets;
 // 3 = 128x128, two sets for the pixel tile only
 static int g_igemm_variant = 3;
@@ -292,7 +295,7 @@ extern "C" int lgen_conv_igemm(const void* a_hi, const void* a_lo, const void* w
         return LGEN_ERR_BAD_ARG;
     if (B == 0 || H * W == 0) return 0;
     IgemmArgs a{(const uint16_t*)a_hi, (const uint16_t*)a_lo, (const uint16_t*)w_hi, (const uint16_t*)w_lo, bias, res, out,
-                H, W, Cin, Cout, Npad, ksize, upsample ? 1 : 0, out_nchw, stride,
+                H, W, Cin, Cout, Npad, ksize, upsample ? 1 : 0, out_nchw, lgen_vq_nt(), stride,
                 stride == 2 ? (long long)(2 * H) * (2 * W) * Cin
                             : (long long)(H >> (upsample ? 1 : 0)) * (W >> (upsample ? 1 : 0)) * Cin,
                 w_bstride, (long long)H * W * Cout, alpha};

@@ -149,6 +149,15 @@ LGEN_DEV uint4 ldg_nt(const uint4* p) {  // streamed-once data (weights): non-te
     return make_uint4(v[0], v[1], v[2], v[3]);
 }
 
+LGEN_DEV float4 ldg_nt_f4(const float4* p) {  // streamed-once fp32 data
+    f32x4_t v = __builtin_nontemporal_load((const f32x4_t*)p);
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+LGEN_DEV void stg_nt_f4(float4* p, float a, float b, float c, float d) {
+    f32x4_t v = {a, b, c, d};
+    __builtin_nontemporal_store(v, (f32x4_t*)p);
+}
+
 LGEN_DEV float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -143,8 +143,12 @@ extern "C" int lgen_vq_argmin(const float* z_nchw, const float* cb_norm, const f
 // group, fixed-order reductions; stage 2 = fp64 combine -> (mean, rstd) per (image, group).
 // ---------------------------------------------------------------------------------------------
 #define GN_THREADS 256
+static int g_vq_nt = 0;
+extern "C" int lgen_set_vq_nt(int v) { g_vq_nt = v ? 1 : 0; return 0; }
+int lgen_vq_nt() { return g_vq_nt; }
+
 __global__ __launch_bounds__(GN_THREADS) void gn_partial_kernel(const float* __restrict__ x, double* __restrict__ part, int hw,
-                                                                int C, int ppc) {
+                                                                int C, int ppc, int nt) {
     __shared__ float s_s[GN_THREADS], s_q[GN_THREADS];
     const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
     const int cq = C >> 2;                       // float4 columns per pixel
@@ -154,7 +158,8 @@ __global__ __launch_bounds__(GN_THREADS) void gn_partial_kernel(const float* __r
     float s = 0.f, q = 0.f;
     if (prow < rows) {
         for (int p = p0 + prow; p < p1; p += rows) {
-            const float4 v = ((const float4*)x)[((size_t)b * hw + p) * cq + col];
+            const float4* vp = (const float4*)x + ((size_t)b * hw + p) * cq + col;
+            const float4 v = nt ? ldg_nt_f4(vp) : *vp;
             s += (v.x + v.y) + (v.z + v.w);
             q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
         }
@@ -191,7 +196,7 @@ extern "C" int lgen_gn_stats(const float* x_nhwc, double* partial_ws, float* sta
     if (B == 0) return 0;
     const int ppc = (hw + nchunk - 1) / nchunk;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, B), dim3(GN_THREADS), 0, st, x_nhwc, partial_ws, hw, C, ppc);
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, B), dim3(GN_THREADS), 0, st, x_nhwc, partial_ws, hw, C, ppc, g_vq_nt);
     LGEN_CHECK_LAUNCH();
     hipLaunchKernelGGL(gn_final_kernel, dim3(B), dim3(32), 0, st, partial_ws, stats, nchunk, (double)hw * (C / 32), eps);
     LGEN_CHECK_LAUNCH();
@@ -204,14 +209,15 @@ extern "C" int lgen_gn_stats(const float* x_nhwc, double* partial_ws, float* sta
 __global__ __launch_bounds__(256) void gn_swish_split_kernel(const float* __restrict__ x, const float* __restrict__ stats,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              uint4* __restrict__ hi, uint4* __restrict__ lo, size_t n8, int hw,
-                                                             int C, int mode) {
+                                                             int C, int mode, int nt) {
     const int c8 = C >> 3;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
         const int col = (int)(i % c8);
         const size_t pix = i / c8;
         const int b = (int)(pix / hw);
         const int c0 = col * 8;
-        const float4 v0 = ((const float4*)x)[i * 2], v1 = ((const float4*)x)[i * 2 + 1];
+        const float4* xp4 = (const float4*)x + i * 2;
+        const float4 v0 = nt ? ldg_nt_f4(xp4) : xp4[0], v1 = nt ? ldg_nt_f4(xp4 + 1) : xp4[1];
         float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
         if (mode & 1) {
             const int gs = C >> 5;
@@ -242,7 +248,7 @@ extern "C" int lgen_gn_swish_split(const float* x_nhwc, const float* stats, cons
     if (n8 == 0) return 0;
     const int blocks = (int)((n8 + 255) / 256 < 16384 ? (n8 + 255) / 256 : 16384);
     hipLaunchKernelGGL(gn_swish_split_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x_nhwc, stats, gamma, beta,
-                       (uint4*)hi, (uint4*)lo, n8, hw, C, mode);
+                       (uint4*)hi, (uint4*)lo, n8, hw, C, mode, g_vq_nt);
     LGEN_CHECK_LAUNCH();
     return 0;
 }

@@ -46,6 +46,9 @@ class _GNW:
 class VQEngine:
     def __init__(self, model):
         self.lib = L.lib()
+        import os
+        if os.environ.get("LGEN_VQ_NT") is not None:  # tuning knob, see lgen_set_vq_nt in lgen.h
+            self.lib.lgen_set_vq_nt(int(os.environ["LGEN_VQ_NT"]))
         self.dev = model.post_quant_conv.weight.device
         cfg = model.config
         self.n_e, self.e_dim, self.l2 = cfg.codebook_size, cfg.codebook_embed_dim, cfg.codebook_l2_norm

@@ -98,3 +98,38 @@ def test_save_codes_format(tmp_path):
     assert cp.endswith("imagenet48_codes/5.npy") and lp.endswith("imagenet48_labels/5.npy")
     f, y = np.load(cp), np.load(lp)
     assert f.dtype == np.int64 and f.shape == (1, 2, 9) and np.array_equal(f[:, 1], codes.numpy()[:, 1]) and y.tolist() == [7]
+
+
+def test_tile_heuristics_are_valid_for_every_registry_model(lib):
+    """engine._tiles must hand the library a tile shape it accepts for every GPT registry size and batch
+    (argument validation runs before the launch; without a GPU the launch itself then fails with a hip error,
+    which is fine here -- LGEN_ERR_BAD_ARG / UNSUPPORTED is not)."""
+    import types
+    from llamagen_amd import _lib as L
+    from llamagen_amd.engine import DecodeEngine, _ceil_div
+    from llamagen_amd.gpt import find_multiple
+    from oracle.llamagen_oracle import GPT_SIZES
+    bad = []
+    for name, sz in GPT_SIZES.items():
+        d, H = sz["dim"], sz["n_head"]
+        F = find_multiple(int(2 * (4 * d) / 3), 256)
+        for dtype, kc in ((L.BF16, 32), (L.F32, 16)):
+            for B2 in (1, 2, 6, 32, 64, 128, 256):
+                mts = _ceil_div(B2, 16)
+                mts = _ceil_div(mts, 8) * 8 if mts > 8 else (8 if mts > 4 else (4 if mts == 3 else mts))
+                kch = d // kc
+                for fuse in (False, True):
+                    fuse = fuse and dtype == L.BF16 and kch % 8 == 0 and 3 <= kch // 8 <= 6
+                    eng = types.SimpleNamespace(tile_override={}, fuse_norm=fuse, mt=min(mts, 4), MTs=mts, kc=kc, lib=lib)
+                    for kind, N, K, epi in (("qkv", 3 * d, d, None), ("wo", d, d, L.EPI_RES), ("w13", 2 * F, d, L.EPI_SWIGLU),
+                                            ("w2", d, F, L.EPI_RES), ("head", 16384, d, L.EPI_ROWS)):
+                        mt, nt, kw = DecodeEngine._tiles(eng, kind, N, K)
+                        nw = 8 if (fuse and kind in ("qkv", "w13", "head")) else 0
+                        if kind == "qkv":
+                            rc = lib.lgen_gemm_qkv_rope(8, 8, 8, 8, 8, 8, 8, B2, mts, d, H, d // H, 64 if d // H <= 64 else 128, 584, 0,
+                                                        dtype, mt, nt, kw, nw, 8 if nw else 0, kch, 1e-5, 0)
+                        else:
+                            rc = lib.lgen_gemm(8, 8, 8, B2, mts, N, K, epi, dtype, mt, nt, kw, nw, 8 if nw else 0, kch, 1e-5, 0, 0)
+                        if rc in (-1, -2):
+                            bad.append((name, dtype, B2, fuse, kind, (mt, nt, kw), rc))
+    assert not bad, bad[:10]

@@ -75,7 +75,7 @@ def measure_attention(gpt, B2, N, npos=12, reps=5):
             def chain():
                 for i in range(e.L):
                     L.check(lib.lgen_attn_decode(L.ptr(e.qbuf), L.ptr(e.k_cache[i]), L.ptr(e.v_cache[i]), L.ptr(e.ap),
-                                                 L.ptr(e.state), 0, B2, e.MTs, e.H, e.hd, e.hdp, e.S8, e.kvs, e.dt, L.stream()), "attn")
+                                                 L.ptr(e.state), 0, 0, B2, e.MTs, e.H, e.hd, e.hdp, e.S8, e.kvs, e.dt, L.stream()), "attn")
             chain()
             stream.synchronize()
             g = torch.cuda.CUDAGraph()

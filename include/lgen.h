@@ -84,10 +84,12 @@ int lgen_gemm_qkv_rope(const void* wp, const void* xp, void* q_out, void* k_cach
 /* Attention.forward back half (gpt.py:229-236): repeat_interleave + math-backend SDPA with
  * causal_mask[:, pos] -- here: single-query attention over the first *pos_ptr+1 cache slots.
  * mask: null = pure causal, else the reference's causal_mask [B2][S8][S8] (1 byte per entry, as
- * modified by generate.py:154-163 for t2i emb_masks); row *pos_ptr of it gates the keys. */
+ * modified by generate.py:154-163 for t2i emb_masks); row *pos_ptr of it gates the keys < mask_len (0 = all
+ * S8; generate.py only ever clears columns of the T-token prefix, so mask_len = T skips the byte loads for
+ * the image tokens). */
 int lgen_attn_decode(const void* q, const void* k_cache, const void* v_cache, void* out_packed, const int* pos_ptr,
-                     const unsigned char* mask, int B2, int MTs, int n_head, int hd, int hdp, int S8, int kv_row_stride,
-                     int dtype, void* stream);
+                     const unsigned char* mask, int mask_len, int B2, int MTs, int n_head, int hd, int hdp, int S8,
+                     int kv_row_stride, int dtype, void* stream);
 
 /* ---- prefix prefill (t2i: all T = cls_token_num caption positions of all B2 rows per layer at once; rows
  * r = t * B2 + b of the packed activations; generate.py:77-86 + gpt.py:348-349 with emb_masks folded into

@@ -40,7 +40,7 @@ SIGNATURES = {
     "lgen_set_weight_nt": [_I],
     "lgen_set_kv_nt": [_I],
     "lgen_set_vq_nt": [_I],
-    "lgen_attn_decode": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "lgen_attn_decode": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "lgen_rope_append_prefill": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "lgen_attn_prefill": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "lgen_sample": [_P, _P, _c.c_longlong, _P, _P, _P, _I, _I, _I, _I, _F, _I, _F, _I, _F, _I, _I, _P],

@@ -205,6 +205,7 @@ struct AttnArgs {
     float sf;            // sqrt(1/sqrt(hd))
     int kvs;             // elements between consecutive cache rows (hdp, or 2*hdp for an interleaved K|V slab)
     int nt;              // K/V loads non-temporal (each row is read once per step; keeps the weights cached)
+    int mask_len;        // only keys < mask_len consult the mask row (t2i: the caption prefix); the rest is pure causal
     const char* pf;      // next kernel's weights (wo), see prefetch_lines in gemm_epilogue.h
     long long pf_bytes;
 };
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(64 * ATT_NW, (ATT_CH <= 2 ? 4 : 2)) void attn_decod
             _Pragma("unroll") for (int e = 0; e < EPL; ++e) dot = fmaf(qf[e], kf[e] * a.sf, dot);  \
             _Pragma("unroll") for (int o = 1; o < LPK; o <<= 1) dot += __shfl_xor(dot, o, 64);     \
             bool vis = key < kvlen;                                                                \
-            if (pm && vis) vis = pm[key] != 0;                                                     \
+            if (pm && vis && key < a.mask_len) vis = pm[key] != 0;                                 \
             s[j] = vis ? dot : -1e30f;                                                             \
             tmax = fmaxf(tmax, s[j]);                                                              \
         }                                                                                          \
@@ -337,10 +338,10 @@ extern "C" int lgen_set_kv_nt(int v) { g_kv_nt = v ? 1 : 0; return 0; }
 extern "C" int lgen_set_attn_variant(int v) { g_attn_variant = v; return 0; }
 
 extern "C" int lgen_attn_decode(const void* q, const void* k_cache, const void* v_cache, void* out_packed,
-                                const int* pos_ptr, const unsigned char* mask, int B2, int MTs, int n_head,
-                                int hd, int hdp, int S8, int kv_row_stride, int dtype, void* stream) {
+                                const int* pos_ptr, const unsigned char* mask, int mask_len, int B2, int MTs,
+                                int n_head, int hd, int hdp, int S8, int kv_row_stride, int dtype, void* stream) {
     AttnArgs a{q, k_cache, v_cache, out_packed, pos_ptr, mask, n_head, hd, hdp, S8, MTs, 0.f,
-               kv_row_stride > 0 ? kv_row_stride : hdp, g_kv_nt, nullptr, 0};
+               kv_row_stride > 0 ? kv_row_stride : hdp, g_kv_nt, mask_len > 0 ? mask_len : S8, nullptr, 0};
     lgen_take_prefetch_hint(&a.pf, &a.pf_bytes);
     a.sf = sqrtf(1.0f / sqrtf((float)hd));
     hipStream_t st = (hipStream_t)stream;

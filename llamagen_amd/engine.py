@@ -285,7 +285,7 @@ class DecodeEngine:
                 e0.record()
             hint(w["wo"])
             L.check(lib.lgen_attn_decode(L.ptr(self.qbuf), L.ptr(self.k_cache[i]), L.ptr(self.v_cache[i]), L.ptr(self.ap),
-                                         pos_ptr, L.ptr(pm), M, mts, H, hd, hdp, S8, self.kvs, dt, st), "attn_decode")
+                                         pos_ptr, L.ptr(pm), self.T if pm is not None else 0, M, mts, H, hd, hdp, S8, self.kvs, dt, st), "attn_decode")
             if self._prof is not None:
                 e1.record()
                 self._prof["events"].append((e0, e1))

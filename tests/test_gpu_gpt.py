@@ -249,7 +249,7 @@ def test_qkv_rope_append_and_attention(dt, B2, H, hd, grid, pos, interleave):
             mask |= torch.eye(S8, dtype=torch.bool)
         out = torch.zeros(d // kcd, mts, 64, kcd // 4, dtype=dt, device=dev)
         md = mask.to(dev).contiguous() if use_mask else None
-        L.check(L.lib().lgen_attn_decode(L.ptr(q_d), L.ptr(kc_d), L.ptr(vc_d), L.ptr(out), L.ptr(state), L.ptr(md), B2, mts, H,
+        L.check(L.lib().lgen_attn_decode(L.ptr(q_d), L.ptr(kc_d), L.ptr(vc_d), L.ptr(out), L.ptr(state), L.ptr(md), 0, B2, mts, H,
                                          hd, hdp, S8, KVS, code, L.stream()), "attn")
         ref = O.sdpa_math(xq.transpose(1, 2), kref, vref, mask[:, None, pos:pos + 1], dt)  # [B,H,1,hd]
         _close(unpack_act(out, B2), ref.transpose(1, 2).reshape(B2, d), dt, f"attn mask={use_mask} variant={variant}")

@@ -96,7 +96,7 @@ def main(name="GPT-L", B=32, img=384):
             e.state.copy_(torch.tensor([pos, pos], dtype=torch.int32, device=dev))
             def fa():
                 for i in range(nl):
-                    L.check(lib.lgen_attn_decode(L.ptr(e.qbuf), L.ptr(e.k_cache[i]), L.ptr(e.v_cache[i]), L.ptr(e.ap), L.ptr(e.state), 0,
+                    L.check(lib.lgen_attn_decode(L.ptr(e.qbuf), L.ptr(e.k_cache[i]), L.ptr(e.v_cache[i]), L.ptr(e.ap), L.ptr(e.state), 0, 0,
                                                  M, mts, H, hd, hdp, S8, e.kvs, dt, st()), "attn")
             report(f"attn variant {variant} pos {pos}", fa, nl, (pos + 1) * 2 * H * hd * 2 * M)
     lib.lgen_set_attn_variant(2)

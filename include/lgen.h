@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define LGEN_ABI_VERSION 2
+#define LGEN_ABI_VERSION 3
 #define LGEN_BF16 0
 #define LGEN_F32 1
 

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblgen_hip.so")
 BF16, F32 = 0, 1
 EPI_ROWS, EPI_PACKED, EPI_GELU, EPI_RES, EPI_SWIGLU, EPI_QKV = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 2
+ABI_VERSION = 3
 ERR_UNSUPPORTED = -2
 
 _c = ctypes

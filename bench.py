@@ -271,7 +271,7 @@ def main():
             res["roofline_vq_decode"] = {"bound": "mfma", "kernel": "igemm_kernel (+ GroupNorm/split passes)", "achieved": round(tf, 1),
                                          "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
                                          "ms_per_decode_code": round(vq_ms, 2), "flop_per_image_fp32": 570.1e9, "mfma_passes": 3}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported at N=1 only (the other ranks would idle in the barrier)
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)
     if world > 1:

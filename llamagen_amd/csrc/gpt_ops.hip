@@ -378,7 +378,8 @@ extern "C" int lgen_attn_decode(const void* q, const void* k_cache, const void* 
 //                              q rows [R][H][hdp], K/V appended at cache slot t of (b, h)
 //   lgen_attn_prefill        : masked causal attention of the prefix onto itself (gpt.py:229-236), fp32
 //                              math-SDPA semantics, output packed for the wo GEMM
-// T is small (120): plain VALU kernels, K/V of one (b, h) staged in LDS as fp32.
+// T <= 128 (the 120-token caption prefix): K/V of one (b, h) staged whole in LDS as fp32; longer sequences
+// take the key-tiled kernel below.  Plain VALU kernels (an evaluation path, not the sampling loop).
 // ---------------------------------------------------------------------------------------------
 template <typename D>
 __global__ __launch_bounds__(256) void rope_append_prefill_kernel(const uint4* __restrict__ qkvp, void* __restrict__ qrows,
@@ -505,12 +506,143 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const void* __restric
     }
 }
 
+// Any-length variant (T > PF_MAXT: full-sequence teacher-forced forward, gpt.py:341-346 + is_causal SDPA of
+// gpt.py:232-236): one workgroup per (b, h, tile of `qt` query rows); K/V stream through LDS in tiles of
+// PFT_KT keys (fp32, scaled like the short kernel) with the running (max, sum, accumulator) of every query
+// row kept in LDS -- the usual online-softmax recurrence, fp32 throughout, one rounding at the store.
+#define PFT_KT 128
+template <typename D>
+__global__ __launch_bounds__(256) void attn_prefill_tiled_kernel(const void* __restrict__ qrows, const void* __restrict__ kc,
+                                                                 const void* __restrict__ vc, void* __restrict__ out,
+                                                                 const unsigned char* __restrict__ mask, int T, int B2, int MTs,
+                                                                 int H, int hd, int hdp, int S8, int kvs, float sf, int qt) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int ld = hd + 1;
+    float* Ks = sm;                              // [PFT_KT][ld], pre-scaled by sf
+    float* Vs = Ks + (size_t)PFT_KT * ld;        // [PFT_KT][ld]
+    float* Qs = Vs + (size_t)PFT_KT * ld;        // [qt][hd], pre-scaled by sf
+    float* Os = Qs + (size_t)qt * hd;            // [qt][hd] running sum of p * v
+    float* Ps = Os + (size_t)qt * hd;            // [4 waves][PFT_KT]
+    float* Ms = Ps + 4 * PFT_KT;                 // [qt] running max
+    float* Ls = Ms + qt;                         // [qt] running sum of p
+    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    const int q0 = blockIdx.y * qt;
+    const int qn = min(qt, T - q0);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int i = tid; i < qt * hd; i += 256) {
+        const int ti = i / hd, dd = i - ti * hd;
+        float q = 0.f;
+        if (ti < qn) q = D::ld(qrows, ((size_t)((size_t)(q0 + ti) * B2 + b) * H + h) * hdp + dd) * sf;
+        Qs[i] = q;
+        Os[i] = 0.f;
+    }
+    if (tid < qt) {
+        Ms[tid] = -INFINITY;
+        Ls[tid] = 0.f;
+    }
+    const int kend = q0 + qn;  // causal: keys 0 .. kend-1 can matter to this tile
+    for (int k0 = 0; k0 < kend; k0 += PFT_KT) {
+        const int kn = min(PFT_KT, kend - k0);
+        __syncthreads();  // previous tile consumed (first pass: Q / O / M / L staged)
+        for (int i = tid; i < kn * hd; i += 256) {
+            const int s = i / hd, dd = i - s * hd;
+            const size_t o = (((size_t)b * H + h) * S8 + k0 + s) * kvs + dd;
+            Ks[s * ld + dd] = D::ld(kc, o) * sf;
+            Vs[s * ld + dd] = D::ld(vc, o);
+        }
+        __syncthreads();
+        for (int ti = wv; ti < qn; ti += 4) {
+            const int t = q0 + ti;
+            if (k0 > t) continue;  // the whole tile lies in this row's future (wave-uniform)
+            const unsigned char* mrow = mask ? mask + ((size_t)b * S8 + t) * S8 : nullptr;
+            const float m_old = Ms[ti], l_old = Ls[ti];
+            float sc[2];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int s = lane + u * 64;
+                const int key = k0 + s;
+                float v = -INFINITY;
+                if (s < kn && key <= t && (!mrow || mrow[key])) {
+                    float dot = 0.f;
+                    for (int dd = 0; dd < hd; ++dd) dot = fmaf(Qs[ti * hd + dd], Ks[s * ld + dd], dot);
+                    v = dot;
+                }
+                sc[u] = v;
+                mx = fmaxf(mx, v);
+            }
+            mx = wave_max(mx);
+            const float m_new = fmaxf(m_old, mx);
+            if (!(m_new > -INFINITY)) continue;  // nothing visible so far (wave-uniform)
+            const float alpha = m_old > -INFINITY ? expf(m_old - m_new) : 0.f;
+            float sum = 0.f;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const float p = sc[u] > -INFINITY ? expf(sc[u] - m_new) : 0.f;
+                Ps[wv * PFT_KT + lane + u * 64] = p;
+                sum += p;
+            }
+            sum = wave_sum(sum);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int nk = min(kn, t - k0 + 1);
+            for (int dd = lane; dd < hd; dd += 64) {
+                float acc = Os[ti * hd + dd] * alpha;
+                for (int s = 0; s < nk; ++s) acc = fmaf(Ps[wv * PFT_KT + s], Vs[s * ld + dd], acc);
+                Os[ti * hd + dd] = acc;
+            }
+            if (lane == 0) {
+                Ms[ti] = m_new;
+                Ls[ti] = l_old * alpha + sum;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+    // rows ti = wv (mod 4) were only ever touched by this wave
+    for (int ti = wv; ti < qn; ti += 4) {
+        const int r = (q0 + ti) * B2 + b;
+        const float l = Ls[ti];
+        for (int dd = lane; dd < hd; dd += 64) D::st(out, D::xp_off(h * hd + dd, r >> 4, r & 15, MTs), Os[ti * hd + dd] / l);
+    }
+}
+
+template <typename D>
+static int launch_attn_prefill_tiled(const void* q_rows, const void* k_cache, const void* v_cache, void* out_packed,
+                                     const unsigned char* mask, int T, int B2, int MTs, int n_head, int hd, int hdp, int S8, int kvs,
+                                     float sf, hipStream_t st) {
+    int qt = 32;
+    auto lds_for = [&](int q) { return ((size_t)2 * PFT_KT * (hd + 1) + (size_t)2 * q * hd + 4 * PFT_KT + 2 * q) * sizeof(float); };
+    while (qt > 4 && lds_for(qt) > 160 * 1024) qt >>= 1;
+    const size_t lds = lds_for(qt);
+    if (lds > 160 * 1024) return LGEN_ERR_BAD_ARG;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)attn_prefill_tiled_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(attn_prefill_tiled_kernel<D>, dim3(B2 * n_head, (T + qt - 1) / qt), dim3(256), lds, st, q_rows, k_cache, v_cache,
+                       out_packed, mask, T, B2, MTs, n_head, hd, hdp, S8, kvs, sf, qt);
+    LGEN_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int lgen_attn_prefill(const void* q_rows, const void* k_cache, const void* v_cache, void* out_packed,
                                  const unsigned char* mask, int T, int B2, int MTs, int n_head, int hd, int hdp, int S8,
                                  int kv_row_stride, int dtype, void* stream) {
-    if (T < 1 || T > PF_MAXT || T > S8 || B2 * T > MTs * 16) return LGEN_ERR_BAD_ARG;
+    if (T < 1 || T > S8 || (long long)B2 * T > (long long)MTs * 16) return LGEN_ERR_BAD_ARG;
     const int kvs = kv_row_stride > 0 ? kv_row_stride : hdp;
     const float sf = sqrtf(1.0f / sqrtf((float)hd));
+    if (T > PF_MAXT) {
+        if (dtype == LGEN_BF16)
+            return launch_attn_prefill_tiled<BF16>(q_rows, k_cache, v_cache, out_packed, mask, T, B2, MTs, n_head, hd, hdp, S8, kvs, sf,
+                                                   (hipStream_t)stream);
+        if (dtype == LGEN_F32)
+            return launch_attn_prefill_tiled<F32>(q_rows, k_cache, v_cache, out_packed, mask, T, B2, MTs, n_head, hd, hdp, S8, kvs, sf,
+                                                  (hipStream_t)stream);
+        return LGEN_ERR_BAD_ARG;
+    }
     const size_t lds = ((size_t)2 * T * (hd + 1) + 4 * PF_MAXT + 4 * hd) * sizeof(float);
     if (lds > 160 * 1024) return LGEN_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;

@@ -355,15 +355,17 @@ class DecodeEngine:
         return out[: B2 * T].view(B2, T, self.d)
 
     # ---- prefix prefill (t2i): all T caption positions through each layer at once -----------------------
-    def _prefill_prefix(self, emb: torch.Tensor):
-        """emb [B2, T, d] (CaptionEmbedder output) -> fills KV slots 0..T-1 of every layer and leaves the
-        residual stream of the LAST prefix position in the decode workspace (self.hp).  Same per-row math as
-        feeding the T positions one by one (rows are independent except through the masked attention), with
-        rows r = t * B2 + b of a [B2*T]-row packed activation set; stand-alone RMSNorm kernels (the fused
-        GEMMs are tuned for M <= 256)."""
+    def _run_sequence(self, emb: torch.Tensor):
+        """emb [B2, S, d] -> all S positions of all rows through every layer at once (causal, plus the folded
+        `emb_masks` when a t2i mask is active): fills KV slots 0..S-1 of every layer and returns the workspace
+        whose "hp" holds the final residual stream, rows r = t * B2 + b of a [B2*S]-row packed activation set.
+        Same per-row math as feeding the positions one by one (rows are independent except through the
+        attention); stand-alone RMSNorm kernels (the fused GEMMs are tuned for M <= 256)."""
         lib, st, dt = self.lib, L.stream(), self.dt
         B2, T, d = emb.shape
         F, H, hd, hdp, S8 = self.F, self.H, self.hd, self.hdp, self.S8
+        if B2 != self.B2 or T > S8:
+            raise ValueError(f"sequence forward of [{B2}, {T}] rows on caches set up for [{self.B2}, {S8}]")
         R = B2 * T
         mts = _ceil_div(R, 16)
         mts = _ceil_div(mts, 8) * 8 if mts > 4 else (4 if mts == 3 else mts)
@@ -371,7 +373,7 @@ class DecodeEngine:
         ws = getattr(self, "_pf_ws", None)
         if ws is None or ws["key"] != key:
             z = lambda *s_: torch.zeros(*s_, dtype=self.dtype, device=self.dev)
-            ws = dict(key=key, hp=z(d // self.kc, mts, 64, self.epl), xn=z(d // self.kc, mts, 64, self.epl),
+            ws = dict(key=key, R=R, mts=mts, hp=z(d // self.kc, mts, 64, self.epl), xn=z(d // self.kc, mts, 64, self.epl),
                       ap=z(d // self.kc, mts, 64, self.epl), gp=z(F // self.kc, mts, 64, self.epl),
                       qkv=z(3 * d // self.kc, mts, 64, self.epl), q=z(mts * 16, H, hdp))
             self._pf_ws = ws
@@ -392,8 +394,38 @@ class DecodeEngine:
             L.check(lib.lgen_rmsnorm(L.ptr(ws["hp"]), L.ptr(w["fn"]), L.ptr(ws["xn"]), mts, d, self.eps, dt, st), "rmsnorm")
             self.gemm(w["w13"], ws["xn"], ws["gp"], R, mts, 2 * F, d, L.EPI_SWIGLU, (mt, 2, max(1, min(8, (d // self.kc) // 2))))
             self.gemm(w["w2"], ws["gp"], ws["hp"], R, mts, d, F, L.EPI_RES, tile(d, F))
-        last = unpack_act(ws["hp"], R)[(T - 1) * B2:]
+        return ws
+
+    def _prefill_prefix(self, emb: torch.Tensor):
+        """emb [B2, T, d] (CaptionEmbedder output) -> KV slots 0..T-1 of every layer filled, residual stream of
+        the LAST prefix position left in the decode workspace (self.hp)."""
+        B2, T, _ = emb.shape
+        ws = self._run_sequence(emb)
+        last = unpack_act(ws["hp"], ws["R"])[(T - 1) * B2:]
         self._set_residual(last)
+
+    def forward_sequence(self, model, idx, cond_idx):
+        """Teacher-forced forward over a whole sequence (gpt.py:341-346, 357-368 with `is_causal` attention):
+        rows = cls_embedding(cond_idx)[:, :T] ++ tok_embeddings(idx) -> fp32 logits [B, T + n, V] (values carry
+        the storage dtype's rounding, gpt.py:368).  The reference runs this shape without KV caches; here the
+        K/V of every position land in the engine's slabs (slots 0..T+n-1) as a side effect."""
+        if model.model_type == "c2i":
+            cond = self.cls_emb[cond_idx.reshape(-1).long()].unsqueeze(1)       # LabelEmbedder, eval (gpt.py:78-83)
+        else:
+            cond = self.caption_embed(cond_idx)                                    # CaptionEmbedder (gpt.py:110-131)
+        cond = cond[:, : self.T]
+        emb = torch.cat([cond, self.tok_emb[idx.long()]], dim=1)                  # [B, T + n, d]
+        B2, S, d = emb.shape
+        masked, self.use_mask = self.use_mask, False  # this shape is `is_causal` in the reference (gpt.py:234), no emb_masks
+        try:
+            ws = self._run_sequence(emb)
+        finally:
+            self.use_mask = masked
+        lib, st, dt, mts, R = self.lib, L.stream(), self.dt, ws["mts"], ws["R"]
+        L.check(lib.lgen_rmsnorm(L.ptr(ws["hp"]), L.ptr(self.norm_w), L.ptr(ws["xn"]), mts, d, self.eps, dt, st), "rmsnorm")
+        lg = torch.empty(mts * 16, self.V, dtype=self.dtype, device=self.dev)
+        self.gemm(self.out_w, ws["xn"], lg, R, mts, self.V, d, L.EPI_ROWS, (min(mts, 4), 1, max(1, min(8, (d // self.kc) // 2))))
+        return lg[:R].view(S, B2, self.V).transpose(0, 1).float().contiguous()
 
     def _final_logits(self):
         """norm + output on the decode workspace (gpt.py:367-368)."""

@@ -19,6 +19,7 @@ from typing import List, Optional
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 
 def find_multiple(n: int, k: int) -> int:
@@ -206,10 +207,31 @@ class Transformer(nn.Module):
             b.attention.kv_cache = KVCacheView(eng.k_cache[i], eng.v_cache[i])
 
     def forward(self, idx, cond_idx, input_pos=None, targets=None, mask=None, valid=None):
-        """Inference branches of gpt.py:332-382: prefill (idx None, cond_idx given) and
-        KV-cached decode (cond_idx None).  Returns (fp32 logits [B, S, V], None)."""
-        if (idx is not None and cond_idx is not None) or targets is not None or self.training:
-            raise NotImplementedError("training / teacher-forced forward is outside the sampling hot path")
+        """gpt.py:332-382 in eval mode.  Prefill (idx None, cond_idx given) and KV-cached decode (cond_idx None)
+        return (fp32 logits [B, S, V], None).  With BOTH idx and cond_idx the whole sequence
+        cls_embedding(cond_idx) ++ tok_embeddings(idx) goes through causally at once (the reference's
+        "training or naive inference" shape, gpt.py:341-346) and `targets` / `valid` produce the cross-entropy of
+        gpt.py:373-380 from those logits; no dropout, no backward (train mode raises)."""
+        if self.training:
+            raise NotImplementedError("train-mode forward (dropout + backward) is outside the sampling hot path")
+        if mask is not None:
+            raise NotImplementedError("explicit attention masks are not part of the reference's call sites for forward")
+        if idx is not None and cond_idx is not None:
+            B, S = idx.shape[0], self.cls_token_num + idx.shape[1]
+            dtype = self.tok_embeddings.weight.dtype
+            if self._engine is None or not self._engine.compatible(self, B, max(find_multiple(S, 8), self.max_seq_length), dtype):
+                self.setup_caches(B, S, dtype)
+            logits = self._engine.forward_sequence(self, idx, cond_idx)
+            loss = None
+            if valid is not None:
+                loss_all = F.cross_entropy(logits.reshape(-1, logits.size(-1)), targets.reshape(-1), reduction="none")
+                valid_all = valid[:, None].repeat(1, targets.shape[1]).reshape(-1)
+                loss = (loss_all * valid_all).sum() / max(valid_all.sum(), 1)
+            elif targets is not None:
+                loss = F.cross_entropy(logits.reshape(-1, logits.size(-1)), targets.reshape(-1))
+            return logits, loss
+        if targets is not None:
+            raise NotImplementedError("targets need the whole-sequence form forward(idx, cond_idx, targets=...)")
         if self._engine is None:
             raise RuntimeError("call setup_caches() before forward (gpt.py:316)")
         return self._engine.forward(self, idx, cond_idx, input_pos), None

@@ -514,6 +514,88 @@ def test_t2i_batched_prefill_matches_sequential(dt, monkeypatch):
         assert torch.equal(t_seq, t_bat)
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("B2,H,hd,T,use_mask", [(3, 2, 64, 300, True), (2, 8, 100, 257, False), (1, 2, 128, 130, True),
+                                                (2, 2, 64, 120, True)])
+def test_attn_prefill_any_length(dt, B2, H, hd, T, use_mask):
+    """lgen_attn_prefill over a whole sequence (rows r = t * B2 + b): the one-tile kernel (T <= 128) and the
+    key-tiled online-softmax kernel (T > 128) against the oracle's math-SDPA restatement (gpt.py:229-236),
+    causal with an optional per-row key mask (generate.py:154-163)."""
+    L = _L()
+    from llamagen_amd.engine import unpack_act
+    dev = _dev()
+    code = L.BF16 if dt == torch.bfloat16 else L.F32
+    hdp = 64 if hd <= 64 else 128
+    d = H * hd
+    S8 = (T + 7) // 8 * 8 + 8
+    R = B2 * T
+    mts = (R + 15) // 16
+    mts = (mts + 7) // 8 * 8 if mts > 4 else (4 if mts == 3 else mts)
+    q = _rand((B2, H, T, hd), dt, 1)
+    k = _rand((B2, H, T, hd), dt, 2)
+    v = _rand((B2, H, T, hd), dt, 3)
+    mask = torch.tril(torch.ones(S8, S8, dtype=torch.bool)).unsqueeze(0).repeat(B2, 1, 1)
+    if use_mask:
+        mask &= torch.rand(B2, 1, S8, generator=torch.Generator().manual_seed(13)) > 0.3
+        mask |= torch.eye(S8, dtype=torch.bool)
+    q_d = torch.zeros(mts * 16, H, hdp, dtype=dt, device=dev)
+    q_d[:R, :, :hd] = q.permute(2, 0, 1, 3).reshape(R, H, hd).to(dev)          # r = t * B2 + b
+    kc_d = torch.randn(B2, H, S8, hdp, device=dev).to(dt)                        # stale slots >= T must not matter
+    vc_d = torch.randn(B2, H, S8, hdp, device=dev).to(dt)
+    kc_d[:, :, :T, :hd] = k.to(dev)
+    vc_d[:, :, :T, :hd] = v.to(dev)
+    kcd = 32 if dt == torch.bfloat16 else 16
+    if d % kcd:
+        pytest.skip("H * hd must be a multiple of the packing chunk")
+    out = torch.zeros(d // kcd, mts, 64, kcd // 4, dtype=dt, device=dev)
+    md = mask.to(dev).contiguous() if use_mask else None
+    L.check(L.lib().lgen_attn_prefill(L.ptr(q_d), L.ptr(kc_d), L.ptr(vc_d), L.ptr(out), L.ptr(md), T, B2, mts, H, hd, hdp, S8, 0,
+                                      code, L.stream()), "attn_prefill")
+    ref = O.sdpa_math(q, k, v, mask[:, None, :T, :T], dt)                        # [B2, H, T, hd]
+    got = unpack_act(out, R).view(T, B2, H, hd).permute(1, 2, 0, 3)
+    _close(got, ref, dt, f"attn_prefill T={T} hd={hd} mask={use_mask}", frac_ulp1=0.05)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_forward_whole_sequence_matches_stepwise(dt):
+    """Transformer.__call__(idx, cond_idx) -- the reference's "training or naive inference" shape
+    (gpt.py:341-346) in eval mode: all T + n positions causally at once (big-M GEMMs, lgen_rope_append_prefill,
+    key-tiled lgen_attn_prefill since T + n > 128) -- must give the logits of the KV-cached position-by-position
+    path (itself pinned to the reference goldens above) and the cross-entropy of gpt.py:373-380."""
+    from llamagen_amd.gpt import ModelArgs, Transformer
+    from llamagen_amd.testing import synth_for_module
+    dev = _dev()
+    kw = dict(n_layer=2, n_head=4, dim=256, vocab_size=512, block_size=144, num_classes=10, cls_token_num=1, model_type="c2i")
+    m = Transformer(ModelArgs(**kw))
+    m.load_state_dict(synth_for_module(m, seed=11, lin_std=0.05), strict=False)
+    m = m.to(device=dev, dtype=dt).eval()
+    B, n = 3, 143
+    g = torch.Generator().manual_seed(5)
+    idx = torch.randint(0, 512, (B, n), generator=g).to(dev)
+    cond = torch.tensor([1, 7, 10], device=dev)
+    targets = torch.randint(0, 512, (B, 1 + n), generator=g).to(dev)
+    m.setup_caches(B, 1 + n, dt)
+    step = [m(None, cond, torch.arange(0, 1, device=dev))[0][:, -1]]
+    for i in range(n):
+        step.append(m(idx[:, i:i + 1], None, torch.tensor([1 + i], device=dev, dtype=torch.int))[0][:, -1])
+    step = torch.stack(step, dim=1).float().cpu()                                  # [B, 1 + n, V]
+    logits, loss = m(idx, cond, targets=targets)
+    assert logits.dtype == torch.float32 and tuple(logits.shape) == (B, 1 + n, 512)
+    whole = logits.cpu()
+    if dt == torch.float32:
+        assert (whole - step).abs().max().item() <= 2e-5 * max(1.0, step.abs().max().item())
+    else:
+        ulp = step.abs().max().item() * 2.0 ** -8
+        err = (whole - step).abs()
+        assert err.max().item() <= 4 * ulp and err.mean().item() <= 0.25 * ulp, (err.max().item(), err.mean().item(), ulp)
+    ref_loss = torch.nn.functional.cross_entropy(whole.reshape(-1, 512), targets.cpu().reshape(-1))
+    assert abs(loss.item() - ref_loss.item()) <= 1e-4 * max(1.0, abs(ref_loss.item()))
+    valid = torch.tensor([1, 0, 1], device=dev)
+    _, lv = m(idx, cond, targets=targets, valid=valid)
+    la = torch.nn.functional.cross_entropy(whole.reshape(-1, 512), targets.cpu().reshape(-1), reduction="none").view(B, -1)
+    assert abs(lv.item() - (la[0].sum() + la[2].sum()).item() / (2 * (1 + n))) <= 1e-4 * max(1.0, abs(lv.item()))
+
+
 def test_full_size_config2_properties(monkeypatch):
     """BASELINE config 2 at full size (GPT-L, 384 px, 32 images, cfg 4.0, top-k 2000, bf16) through size-independent
     properties: ids in range and well spread, same seed -> same ids, hipGraph replay == eager launches, fused-norm

@@ -91,7 +91,7 @@ int lgen_attn_decode(const void* q, const void* k_cache, const void* v_cache, vo
                      const unsigned char* mask, int mask_len, int B2, int MTs, int n_head, int hd, int hdp, int S8,
                      int kv_row_stride, int dtype, void* stream);
 
-/* ---- prefix prefill (t2i: all T = cls_token_num caption positions of all B2 rows per layer at once; rows
+/* ---- sequence prefill (t2i prefix: all T = cls_token_num caption positions of all B2 rows per layer at once; rows
  * r = t * B2 + b of the packed activations; generate.py:77-86 + gpt.py:348-349 with emb_masks folded into
  * causal_mask, generate.py:154-163) ---- */
 
@@ -102,7 +102,9 @@ int lgen_rope_append_prefill(const void* qkv_packed, void* q_rows, void* k_cache
                              int dtype, void* stream);
 
 /* masked causal attention of the prefix onto itself (gpt.py:229-236, math-SDPA semantics): query row (b, t)
- * sees keys s <= t with mask[b][t][s] != 0 (mask = causal_mask [B2][S8][S8] bytes or null); out = XP of width d. */
+ * sees keys s <= t with mask[b][t][s] != 0 (mask = causal_mask [B2][S8][S8] bytes or null); out = XP of width d.
+ * Any 1 <= T <= S8: up to 128 positions keep K/V of one (b, h) whole in LDS; longer sequences (the whole-sequence
+ * `is_causal` forward of gpt.py:232-236, 341-346) take a key-tiled online-softmax kernel. */
 int lgen_attn_prefill(const void* q_rows, const void* k_cache, const void* v_cache, void* out_packed,
                       const unsigned char* mask, int T, int B2, int MTs, int n_head, int hd, int hdp, int S8,
                       int kv_row_stride, int dtype, void* stream);

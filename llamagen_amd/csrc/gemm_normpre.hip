@@ -148,7 +148,8 @@ __global__ __launch_bounds__(512) void gemm_normpre_kernel(GemmArgs a) {
 template <int MT, int NT, int EPI, int CPW>
 static int launch_np(const GemmArgs& a, int kw, hipStream_t st) {
     // shapes whose operand set does not fit 256 VGPRs (they spill; found by compiling everything once):
-    constexpr bool spills = (MT == 4 && CPW == 6) || (MT == 4 && NT >= 2 && EPI == EPI_QKV && CPW >= 5) ||
+    constexpr bool spills = (MT == 4 && CPW == 6) || (MT == 4 && NT == 4 && CPW == 5) ||
+                            (MT == 4 && NT >= 2 && EPI == EPI_QKV && CPW >= 5) ||
                             (MT == 4 && NT == 4 && EPI == EPI_QKV) || (MT == 2 && NT == 4 && EPI == EPI_QKV && CPW == 6);
     if constexpr (spills) {
         return LGEN_ERR_UNSUPPORTED;

@@ -133,3 +133,38 @@ def test_tile_heuristics_are_valid_for_every_registry_model(lib):
                         if rc in (-1, -2):
                             bad.append((name, dtype, B2, fuse, kind, (mt, nt, kw), rc))
     assert not bad, bad[:10]
+
+
+def test_hot_kernels_have_no_register_spills():
+    """The build leaves the compiler's per-kernel resource report next to every object
+    (llamagen_amd/csrc/*.usage, -Rpass-analysis=kernel-resource-usage).  Every kernel of the library must be free
+    of scratch memory except a short list of instantiations no default configuration launches (kept compiled
+    as tuning options); the decode-loop and VQ kernels are checked by family."""
+    import glob
+    import re
+    files = glob.glob(os.path.join(ROOT, "llamagen_amd", "csrc", "*.usage"))
+    if not files:
+        pytest.skip("no resource reports (library not built through the Makefile)")
+    kernels = {}
+    for f in files:
+        cur = None
+        for line in open(f):
+            m = re.search(r"remark: Function Name: (\S+)", line)
+            if m:
+                cur = kernels.setdefault(m.group(1), {})
+                continue
+            m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+)", line)
+            if m and cur is not None:
+                cur[m.group(1).strip()] = int(m.group(2))
+    assert len(kernels) > 100
+    allowed = [r"gemm_kernelI4BF16Li8ELi2ELi\dELb1ELi2E",      # ring-buffer NORM GEMM at mt = 8 (engine uses mt <= 4)
+               r"gemm_kernelI4BF16Li4ELi4ELi5ELb1ELi2E",         # ring-buffer NORM qkv at (4, 4): fused qkv runs (1, 4) / (2, 4)
+               r"rmsnorm_kernelI4BF16Li16E",                     # bf16 rows wider than 4096 (no registry model)
+               r"igemm_kernelILi4ELi4ELi2ELi1E"]                 # conv variant 1 (double-staged both operands), not the default
+    spilled = [n for n, r in kernels.items() if r.get("ScratchSize", 0) > 0 or r.get("VGPRs Spill", 0) > 0]
+    unexpected = [n for n in spilled if not any(re.search(a, n) for a in allowed)]
+    assert not unexpected, unexpected
+    for family in ("attn_decode_kernel", "gemm_normpre_kernel", "sample_kernel", "embed_pack_kernel", "attn_prefill"):
+        members = [n for n in kernels if family in n]
+        assert members, family
+        assert all(kernels[n].get("ScratchSize", 0) == 0 for n in members), family

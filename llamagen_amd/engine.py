@@ -177,6 +177,16 @@ class DecodeEngine:
         # kernel's own operand loads), so it is off; LGEN_PREFETCH=1 re-enables it for experiments.
         self.prefetch = os.environ.get("LGEN_PREFETCH", "0") == "1"
         self.tile_override = {}      # kind ("qkv" | "wo" | "w13" | "w2" | "head") -> (mt, nt, kw)
+        # tuning hook: LGEN_TILES="qkv=2,4,8;wo=4,1,8;w2=4,1,8" (e.g. fewer, fatter workgroups per GEMM so that the
+        # kernels of several in-flight batches share the chip side by side instead of taking turns)
+        for item in filter(None, os.environ.get("LGEN_TILES", "").split(";")):
+            kind, _, val = item.partition("=")
+            if kind.strip() not in ("qkv", "wo", "w13", "w2", "head"):
+                raise ValueError(f"LGEN_TILES: unknown GEMM '{kind}'")
+            t = tuple(int(v) for v in val.split(","))
+            if len(t) != 3:
+                raise ValueError(f"LGEN_TILES: '{item}' is not kind=mt,nt,kw")
+            self.tile_override[kind.strip()] = t
         self._pack(model)
 
     # ---- weights --------------------------------------------------------------------------

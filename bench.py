@@ -167,6 +167,7 @@ def main():
                                                          "0 = pick 1..3 from the step count")
     ap.add_argument("--steps-per-turn", type=int, default=1, help="decode steps a lane enqueues per scheduler turn")
     ap.add_argument("--vq-own-stream", action="store_true", help="decode images on a separate shared stream (measured slower)")
+    ap.add_argument("--lane-cu-mask", action="store_true", help="experiment: every lane's stream owns 1/lanes of the CUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -190,7 +191,8 @@ def main():
         # lanes costs floor(K/L) * T_L + T_(K mod L): use the cheapest L
         T = {0: 0.0, 1: 1.0, 2: 1.44, 3: 2.02}
         args.lanes = min((1, 2, 3), key=lambda l: (args.steps // l) * T[l] + T[args.steps % l])
-    pipe = SamplingPipeline(gpt, vq, lanes=args.lanes, steps_per_turn=args.steps_per_turn, vq_low_priority=args.vq_own_stream)
+    pipe = SamplingPipeline(gpt, vq, lanes=args.lanes, steps_per_turn=args.steps_per_turn, vq_low_priority=args.vq_own_stream,
+                            cu_partition=True if args.lane_cu_mask else None)
     pipe.prepare(BATCH, N, **skw)  # setup (like loading weights): KV slabs, workspaces, decode graphs per lane
     torch.cuda.synchronize()
 

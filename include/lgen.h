@@ -182,6 +182,13 @@ int lgen_set_kv_nt(int v);         /* decode attention K/V loads: 1 (default) no
 int lgen_set_vq_nt(int v);         /* VQ decoder: non-temporal fp32 activation stores / GroupNorm-pass loads (0 = off) */
 int lgen_set_igemm_variant(int v); /* 3 (default): 128x128 tile, 2 staging sets for pixels / 1 for weights; 0: 1 set; 1: 2 full sets; 2: 128x64 tiles */
 
+/* ---- lane streams (host-side plumbing for llamagen_amd/pipeline.py; no reference counterpart) ----
+ * A HIP stream whose kernels may only occupy the CUs whose bit is set in mask_words (bit i of word i/32 = CU i;
+ * hipExtStreamCreateWithCUMask): lets every in-flight batch own a slice of the chip, so that the latency-bound
+ * decode kernels of different batches run side by side instead of taking turns.  *stream_out is a hipStream_t. */
+int lgen_stream_create_cu_mask(const unsigned int* mask_words, int n_words, void** stream_out);
+int lgen_stream_destroy(void* stream);
+
 #ifdef __cplusplus
 }
 #endif

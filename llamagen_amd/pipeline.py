@@ -17,11 +17,34 @@ the default generator batch by batch in submission order, exactly as consecutive
 """
 from __future__ import annotations
 
+import ctypes
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
 
 from .generate import generate_iter
+
+
+def cu_mask_words(n_cu: int, part: int, parts: int) -> List[int]:
+    """32-bit mask words selecting the `part`-th of `parts` contiguous slices of CU bits 0..n_cu-1.  The driver
+    deals consecutive mask bits round-robin over the XCDs, so a contiguous bit range is an (almost) equal share of
+    every XCD -- each lane keeps all eight L2s and one eighth of its CUs behind each."""
+    lo, hi = part * n_cu // parts, (part + 1) * n_cu // parts
+    words = [0] * ((n_cu + 31) // 32)
+    for b in range(lo, hi):
+        words[b // 32] |= 1 << (b % 32)
+    return words
+
+
+def masked_stream(dev: torch.device, words: Sequence[int]):
+    """A torch handle on a HIP stream restricted to the CUs of `words` (lgen_stream_create_cu_mask)."""
+    from . import _lib as L
+    arr = (ctypes.c_uint32 * len(words))(*words)
+    out = ctypes.c_void_p()
+    with torch.cuda.device(dev):
+        L.check(L.lib().lgen_stream_create_cu_mask(arr, len(words), ctypes.byref(out)), "lgen_stream_create_cu_mask")
+    return torch.cuda.ExternalStream(out.value, device=dev)
 
 
 class SamplingLane:
@@ -82,12 +105,23 @@ class SamplingPipeline:
     """Keeps up to `lanes` batches in flight.  run(conds) -> [(ids, images)] in submission order; the
     results are enqueued-behind on the CURRENT stream when run() returns (no host synchronisation)."""
 
-    def __init__(self, gpt, vq=None, lanes: int = 2, steps_per_turn: int = 1, vq_low_priority: bool = False):
+    def __init__(self, gpt, vq=None, lanes: int = 2, steps_per_turn: int = 1, vq_low_priority: bool = False,
+                 cu_partition: Optional[bool] = None):
         self.dev = next(gpt.parameters()).device
         # optional: one shared stream for every lane's VQ decode (see SamplingLane)
         self.vq_stream = torch.cuda.Stream(device=self.dev, priority=0) if (vq is not None and vq_low_priority) else None
-        self.lanes: List[SamplingLane] = [SamplingLane(gpt, vq, primary=(i == 0), vq_stream=self.vq_stream)
-                                          for i in range(max(1, lanes))]
+        lanes = max(1, lanes)
+        # optional (experiment, LGEN_LANE_CU_MASK=1): every lane's stream owns 1/lanes of the CUs, so that the lanes'
+        # kernels run side by side on disjoint CUs instead of each launch spreading over the whole chip
+        if cu_partition is None:
+            cu_partition = os.environ.get("LGEN_LANE_CU_MASK", "0") == "1"
+        streams = [None] * lanes
+        if cu_partition and lanes > 1:
+            n_cu = torch.cuda.get_device_properties(self.dev).multi_processor_count
+            streams = [masked_stream(self.dev, cu_mask_words(n_cu, i, lanes)) for i in range(lanes)]
+        self.cu_partition = bool(cu_partition and lanes > 1)
+        self.lanes: List[SamplingLane] = [SamplingLane(gpt, vq, stream=streams[i], primary=(i == 0), vq_stream=self.vq_stream)
+                                          for i in range(lanes)]
         self.steps_per_turn = steps_per_turn
 
     def prepare(self, batch: int, max_new_tokens: int, **gen_kw):

@@ -168,3 +168,19 @@ def test_hot_kernels_have_no_register_spills():
         members = [n for n in kernels if family in n]
         assert members, family
         assert all(kernels[n].get("ScratchSize", 0) == 0 for n in members), family
+
+
+def test_lane_cu_masks_partition_the_chip():
+    """pipeline.cu_mask_words: the lanes' CU masks are disjoint, cover every CU, and differ by at most one CU."""
+    from llamagen_amd.pipeline import cu_mask_words
+    for n_cu in (256, 304, 64):
+        for parts in (1, 2, 3, 4):
+            masks = [cu_mask_words(n_cu, i, parts) for i in range(parts)]
+            bits = [sum(bin(w).count("1") for w in m) for m in masks]
+            assert sum(bits) == n_cu and max(bits) - min(bits) <= 1
+            for w in range(len(masks[0])):
+                acc = 0
+                for m in masks:
+                    assert acc & m[w] == 0
+                    acc |= m[w]
+            assert all(0 <= w < 2 ** 32 for m in masks for w in m)

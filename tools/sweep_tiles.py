@@ -4,7 +4,8 @@ Hypothesis behind it: with 3 batches in flight the decode 
 because each launch spreads 176-512 workgroups of 512 threads over all 256 CUs; fewer, fatter workgroups per
 GEMM (64-96) would let the three lanes' latency-bound kernels run side by side.
 
-    python tools/sweep_tiles.py            # on a GPU: img/s for every candidate, 3 lanes and 1 lane
+    python tools/sweep_tiles.py            # on a GPU: img/s for every candidate, 3 lanes (shared chip and
+                                           # CU-partitioned lane streams) and 1 lane
     python tools/sweep_tiles.py --check    # no GPU: only validates that the library accepts every candidate
 """
 import os, sys, time
@@ -58,16 +59,16 @@ def main():
     names = sys.argv[1:] or list(CANDIDATES)
     for name in names:
         os.environ["LGEN_TILES"] = CANDIDATES[name]
-        for lanes in (3, 1):
+        for lanes, part in ((3, False), (3, True), (2, True), (4, True), (1, False)):
             gpt._engine = None  # engines read LGEN_TILES when they are built
-            pipe = SamplingPipeline(gpt, vq, lanes=lanes)
+            pipe = SamplingPipeline(gpt, vq, lanes=lanes, cu_partition=part)
             pipe.prepare(B, N, **skw)
-            K = 6 if lanes == 3 else 2
+            K = {1: 2, 2: 4, 3: 6, 4: 8}[lanes]
             conds = [torch.randint(0, 1000, (B,), device=dev) for _ in range(K)]
             torch.cuda.synchronize(); t = time.perf_counter()
             pipe.run(conds, N, **skw)
             torch.cuda.synchronize(); dt = time.perf_counter() - t
-            print(f"{name:14s} lanes={lanes}: {B * K / dt:6.1f} img/s   [{CANDIDATES[name] or 'engine heuristics'}]", flush=True)
+            print(f"{name:14s} lanes={lanes} cu_partition={int(part)}: {B * K / dt:6.1f} img/s   [{CANDIDATES[name] or 'engine heuristics'}]", flush=True)
             del pipe
             torch.cuda.empty_cache()
 

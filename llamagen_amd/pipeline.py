@@ -27,9 +27,10 @@ from .generate import generate_iter
 
 
 def cu_mask_words(n_cu: int, part: int, parts: int) -> List[int]:
-    """32-bit mask words selecting the `part`-th of `parts` contiguous slices of CU bits 0..n_cu-1.  The driver
-    deals consecutive mask bits round-robin over the XCDs, so a contiguous bit range is an (almost) equal share of
-    every XCD -- each lane keeps all eight L2s and one eighth of its CUs behind each."""
+    """32-bit mask words selecting the `part`-th of `parts` contiguous slices of CU bits 0..n_cu-1.  On multi-XCD
+    parts the kernel driver is understood to deal consecutive mask bits round-robin over the XCDs, in which case a
+    contiguous bit range is an (almost) equal share of every XCD -- each lane keeps all eight L2s and one eighth of
+    its CUs behind each.  (Not yet confirmed by measurement on MI355X; part of the round-2 experiment.)"""
     lo, hi = part * n_cu // parts, (part + 1) * n_cu // parts
     words = [0] * ((n_cu + 31) // 32)
     for b in range(lo, hi):

@@ -30,7 +30,7 @@ def cu_mask_words(n_cu: int, part: int, parts: int) -> List[int]:
     """32-bit mask words selecting the `part`-th of `parts` contiguous slices of CU bits 0..n_cu-1.  On multi-XCD
     parts the kernel driver is understood to deal consecutive mask bits round-robin over the XCDs, in which case a
     contiguous bit range is an (almost) equal share of every XCD -- each lane keeps all eight L2s and one eighth of
-    its CUs behind each.  (Not yet confirmed by measurement on MI355X; part of the round-2 experiment.)"""
+    its CUs behind each (the bit-to-XCD mapping itself has not been measured here)."""
     lo, hi = part * n_cu // parts, (part + 1) * n_cu // parts
     words = [0] * ((n_cu + 31) // 32)
     for b in range(lo, hi):
@@ -113,7 +113,9 @@ class SamplingPipeline:
         self.vq_stream = torch.cuda.Stream(device=self.dev, priority=0) if (vq is not None and vq_low_priority) else None
         lanes = max(1, lanes)
         # optional (experiment, LGEN_LANE_CU_MASK=1): every lane's stream owns 1/lanes of the CUs, so that the lanes'
-        # kernels run side by side on disjoint CUs instead of each launch spreading over the whole chip
+        # kernels run side by side on disjoint CUs instead of each launch spreading over the whole chip.  Measured
+        # SLOWER on MI355X (tools/quick_cu_mask.py, decode only, 3 lanes: 69 vs 91 img/s sharing the whole chip;
+        # identical tokens), so it stays off
         if cu_partition is None:
             cu_partition = os.environ.get("LGEN_LANE_CU_MASK", "0") == "1"
         streams = [None] * lanes

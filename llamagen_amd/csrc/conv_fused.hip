@@ -1,0 +1,355 @@
+// Fused VQ-decoder convolution: GroupNorm-apply + swish + hi/lo split on the way INTO the tile, 3x3 / 1x1
+// convolution on MFMA from an LDS-resident halo tile, bias + residual + next-GroupNorm statistics on the way OUT.
+//
+// Replaces, per convolution of the decoder (tokenizer/tokenizer_image/vq_model.py):
+//   Normalize (GroupNorm(32, C, 1e-6), :359-364) + nonlinearity (x*sigmoid(x), :354-356) applied to the conv
+//   input (ResnetBlock.forward :299-306, Decoder.forward :190-192), nn.Conv2d 3x3 pad 1 / 1x1 (:288-291, :167),
+//   F.interpolate(2.0, nearest) in front of Upsample.conv (:374-378), the residual add of ResnetBlock (:314) and
+//   the statistics pass of the NEXT GroupNorm (per-(image, group) sum / sum of squares of this conv's output).
+//
+// Why (round-1 profile): the un-fused form read every conv input three times as fp32 (statistics, apply/split,
+// then the (hi, lo) planes again) and staged each pixel tile from L2 once per filter tap.  Here
+//   * the input is read ONCE per K-chunk as fp32 (tile + 1-pixel halo), normalised / activated / split in
+//     registers and kept in LDS as (hi, lo) bf16 for all nine taps: staging traffic per tap is the weight tile only;
+//   * the 3-pass split-bf16 product (hi*hi + hi*lo + lo*hi, fp32 accumulate on v_mfma_f32_16x16x32_bf16) is
+//     unchanged: <= 1.3e-4 abs against the fp32 reference decoder (single-pass bf16: 9e-2);
+//   * the epilogue reduces per-(tile, 4-channel quad) sums of the stored fp32 values, so the consumer's
+//     GroupNorm needs no pass over the activation (lgen_gn_finalize turns the partials into per-channel
+//     (scale, shift) pairs).
+//
+// Tile: 8 rows x 16 columns of one image x BN output channels per 256-thread workgroup (4 waves as
+// WNW x WMW; each wave JN x JM 16x16 MFMA tiles), two workgroups per CU so that one's HBM-bound prologue /
+// epilogue overlaps the other's MFMA phase (at C = 128 these convolutions sit near the HBM/MFMA balance point:
+// 7.2 GB of fp32 traffic vs 4.2 TFLOP of split-bf16 MFMA work per 32-image 384 px conv).
+// LDS: halo tile [plane][k-slice fg][pixel][8 ch] (pixel-major inside a k-slice slab whose size is a
+// multiple of 256 B: the B-operand `ds_read_b128` of 16 consecutive pixels is bank-conflict free for EVERY
+// tap shift), weights in MFMA fragment order (lane-linear, conflict free), double-buffered per tap.
+#include "lgen_common.h"
+#include "../../include/lgen.h"
+
+struct ConvFArgs {
+    const float* x;      // [B][Hs][Ws][Cin] fp32 NHWC (Hs = H >> ups)
+    const float2* coef;  // [B][Cin] (scale, shift) of the fused GroupNorm, or null
+    const uint4* w;      // [Npad/BN][Cin/32][taps][2 planes][BN/16][64 lanes] x 16 B (MFMA A-fragment order)
+    const float* bias;   // [Cout] or null
+    const float* res;    // NHWC like out, or null
+    float* out;          // NHWC [B][H][W][Cout] (or NCHW)
+    float* part;         // [B][ntiles][Npad/4][2] partial (sum, sumsq) of the stored output, or null
+    int H, W, Cin, Cout, Npad, ups, swish, out_nchw, tiles_x, ntiles;
+};
+
+LGEN_DEV void split8(const float (&f)[8], uint4& hi, uint4& lo) {
+    float r[8];
+    hi = BF16::pack(f);
+    float h[8];
+    BF16::unpack(hi, h);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = f[e] - h[e];
+    lo = BF16::pack(r);
+}
+
+template <int JN, int WNW, int KS>
+__global__ __launch_bounds__(256, 2) void conv_fused_kernel(ConvFArgs a) {
+    constexpr int PAD = KS / 2, TH = 8, TW = 16, TAPS = KS * KS;
+    constexpr int WMW = 4 / WNW, JM = TH / WMW;
+    constexpr int BN = WNW * JN * 16;
+    constexpr int HR = TH + 2 * PAD, HC = TW + 2 * PAD, NP = HR * HC, NPP = (NP + 15) / 16 * 16;
+    constexpr int ITER = (NP * 4 + 255) / 256;
+    constexpr int FGS = NPP * 16;               // bytes of one k-slice slab
+    constexpr int PLANE = 4 * FGS;              // bytes of one (hi | lo) plane
+    constexpr int HALO = 2 * PLANE;
+    constexpr int WT = 2 * (BN / 16) * 1024;    // bytes of one tap's weight tile (hi + lo fragments)
+    constexpr int W_IT = (WT / 16 + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sH = smem;
+    unsigned char* sW = smem + HALO;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wn = wv % WNW, wm = wv / WNW;
+    const int b = blockIdx.z, nb = blockIdx.y;
+    // XCD-aware tile order: consecutive workgroup ids land on different XCDs (id % 8), so give each XCD a
+    // contiguous run of tiles (neighbouring tiles share halo rows and all share the weights in that XCD's L2)
+    int tile = blockIdx.x;
+    {
+        const int nt = a.ntiles, q = nt >> 3, r = nt & 7, xcd = tile & 7, k = tile >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int y0 = (tile / a.tiles_x) * TH, x0 = (tile % a.tiles_x) * TW;
+    const int Hs = a.H >> a.ups, Ws = a.W >> a.ups;
+    const int nkc = a.Cin >> 5;
+    const int nsteps = nkc * TAPS;
+    const float* xb = a.x + (size_t)b * Hs * Ws * a.Cin;
+
+    // per-thread halo staging items: it = t + i*256 -> (pixel P = it >> 2, k-slice fg = it & 3)
+    int soff[ITER];
+    bool sok[ITER];
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) {
+        const int it = t + i * 256;
+        const int P = (it >> 2) < NP ? (it >> 2) : NP - 1;
+        const int hy = P / HC, hx = P - hy * HC;
+        const int yy = y0 - PAD + hy, xx = x0 - PAD + hx;
+        sok[i] = (it < NP * 4) && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+        const int sy = sok[i] ? (yy >> a.ups) : 0, sx = sok[i] ? (xx >> a.ups) : 0;
+        soff[i] = (sy * Ws + sx) * a.Cin + (it & 3) * 8;
+    }
+    const int fg_t = t & 3;
+    float4 raw[ITER][2];
+    float4 cf[4];  // 8 (scale, shift) pairs of this thread's channels in the chunk
+#define CF_GLOAD_HALO(kc_)                                                                          \
+    {                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < ITER; ++i) {                                          \
+            const float4* p = (const float4*)(xb + soff[i] + (kc_) * 32);                           \
+            raw[i][0] = p[0];                                                                       \
+            raw[i][1] = p[1];                                                                       \
+        }                                                                                           \
+        if (a.coef) {                                                                               \
+            const float4* c = (const float4*)(a.coef + (size_t)b * a.Cin + (kc_) * 32 + fg_t * 8);  \
+            cf[0] = c[0]; cf[1] = c[1]; cf[2] = c[2]; cf[3] = c[3];                                 \
+        }                                                                                           \
+    }
+    auto store_halo = [&]() {
+        const float* cff = (const float*)cf;
+#pragma unroll
+        for (int i = 0; i < ITER; ++i) {
+            const int it = t + i * 256;
+            if (i + 1 < ITER || it < NP * 4) {
+                float f[8] = {raw[i][0].x, raw[i][0].y, raw[i][0].z, raw[i][0].w, raw[i][1].x, raw[i][1].y, raw[i][1].z, raw[i][1].w};
+                if (a.coef) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = fmaf(f[e], cff[2 * e], cff[2 * e + 1]);
+                }
+                if (a.swish) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = f[e] / (1.0f + expf(-f[e]));
+                }
+                uint4 hi, lo;
+                split8(f, hi, lo);
+                const unsigned m_ = sok[i] ? 0xffffffffu : 0u;  // conv zero padding applies AFTER norm / swish
+                const int o = (it & 3) * FGS + (it >> 2) * 16;
+                *(uint4*)(sH + o) = make_uint4(hi.x & m_, hi.y & m_, hi.z & m_, hi.w & m_);
+                *(uint4*)(sH + PLANE + o) = make_uint4(lo.x & m_, lo.y & m_, lo.z & m_, lo.w & m_);
+            }
+        }
+    };
+    uint4 wreg[W_IT];
+    const uint4* wbase = a.w + (size_t)nb * nkc * TAPS * (WT / 16);
+#define CF_GLOAD_W(step_)                                                                           \
+    {                                                                                               \
+        const int st_ = (step_) < nsteps ? (step_) : nsteps - 1;                                    \
+        _Pragma("unroll") for (int i = 0; i < W_IT; ++i) {                                          \
+            const int idx = t + i * 256;                                                            \
+            wreg[i] = wbase[(size_t)st_ * (WT / 16) + (idx < WT / 16 ? idx : 0)];                   \
+        }                                                                                           \
+    }
+#define CF_LSTORE_W(buf_)                                                                           \
+    {                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < W_IT; ++i) {                                          \
+            const int idx = t + i * 256;                                                            \
+            if (W_IT * 256 == WT / 16 || idx < WT / 16) *(uint4*)(sW + (buf_) * WT + idx * 16) = wreg[i]; \
+        }                                                                                           \
+    }
+
+    f32x4_t acc[JN][JM];
+#pragma unroll
+    for (int j = 0; j < JN; ++j)
+#pragma unroll
+        for (int i = 0; i < JM; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fg = lane >> 4;
+    auto compute = [&](int wbuf, int tap) {
+        const int ty = tap / KS, tx = tap - ty * KS;
+        const unsigned char* hb = sH + fg * FGS + (size_t)((wm * JM + ty) * HC + fr + tx) * 16;
+        uint4 phi[JM], plo[JM];
+#pragma unroll
+        for (int i = 0; i < JM; ++i) {
+            phi[i] = *(const uint4*)(hb + i * HC * 16);
+            plo[i] = *(const uint4*)(hb + PLANE + i * HC * 16);
+        }
+        const unsigned char* wb = sW + wbuf * WT + lane * 16;
+#pragma unroll
+        for (int j = 0; j < JN; ++j) {
+            const uint4 wh = *(const uint4*)(wb + (wn * JN + j) * 1024);
+            const uint4 wl = *(const uint4*)(wb + (BN / 16 + wn * JN + j) * 1024);
+#pragma unroll
+            for (int i = 0; i < JM; ++i) {
+                acc[j][i] = BF16::mma(wl, phi[i], acc[j][i]);
+                acc[j][i] = BF16::mma(wh, plo[i], acc[j][i]);
+                acc[j][i] = BF16::mma(wh, phi[i], acc[j][i]);
+            }
+        }
+    };
+
+    CF_GLOAD_HALO(0);
+    CF_GLOAD_W(0);
+    for (int kc = 0; kc < nkc; ++kc) {
+        // every wave has finished reading the previous chunk's halo (barrier at the end of its last tap)
+        store_halo();
+        if (kc == 0) CF_LSTORE_W(0);
+        __syncthreads();
+        if (kc + 1 < nkc) CF_GLOAD_HALO(kc + 1);  // lands during the taps of this chunk
+#pragma unroll 1
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int s = kc * TAPS + tap;
+            CF_GLOAD_W(s + 1);
+            compute(s & 1, tap);
+            CF_LSTORE_W((s + 1) & 1);
+            __syncthreads();
+        }
+    }
+#undef CF_GLOAD_HALO
+#undef CF_GLOAD_W
+#undef CF_LSTORE_W
+
+    // epilogue: lane holds channels n = n0 + g*4 + {0..3} of pixel (y0 + row, x0 + fr)
+    const size_t HW = (size_t)a.H * a.W;
+    float* outb = a.out + (size_t)b * HW * a.Cout;
+    const float* resb = a.res ? a.res + (size_t)b * HW * a.Cout : nullptr;
+    float* red = (float*)smem;  // [WMW][BN/4][2] after the main loop (all LDS reads are behind the last barrier)
+#pragma unroll
+    for (int j = 0; j < JN; ++j) {
+        const int nl = (wn * JN + j) * 16 + fg * 4;
+        const int n = nb * BN + nl;
+        float bs[4] = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bs[e] = n + e < a.Cout ? a.bias[n + e] : 0.f;
+        }
+        float ssum = 0.f, sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < JM; ++i) {
+            const int y = y0 + wm * JM + i, x = x0 + fr;
+            const size_t p = (size_t)y * a.W + x;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[j][i][e] + bs[e];
+            if (!a.out_nchw && n + 3 < a.Cout) {
+                const size_t o = p * a.Cout + n;
+                if (resb) {
+                    const float4 r = *(const float4*)(resb + o);
+                    v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+                }
+                *(float4*)(outb + o) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (n + e >= a.Cout) { v[e] = 0.f; continue; }
+                    const size_t o = a.out_nchw ? (size_t)(n + e) * HW + p : p * a.Cout + n + e;
+                    if (resb) v[e] += resb[o];
+                    outb[o] = v[e];
+                }
+            }
+            ssum += (v[0] + v[1]) + (v[2] + v[3]);
+            sq += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        }
+        if (a.part) {  // fixed-order reduction over the 16 pixels of the lane group, then over wm through LDS
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                ssum += __shfl_xor(ssum, o, 64);
+                sq += __shfl_xor(sq, o, 64);
+            }
+            if (fr == 0) {
+                red[(wm * (BN / 4) + (nl >> 2)) * 2 + 0] = ssum;
+                red[(wm * (BN / 4) + (nl >> 2)) * 2 + 1] = sq;
+            }
+        }
+    }
+    if (a.part) {
+        __syncthreads();
+        if (t < BN / 4) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int w = 0; w < WMW; ++w) {
+                s += red[(w * (BN / 4) + t) * 2 + 0];
+                q += red[(w * (BN / 4) + t) * 2 + 1];
+            }
+            float* dst = a.part + (((size_t)b * a.ntiles + tile) * (a.Npad / 4) + nb * (BN / 4) + t) * 2;
+            dst[0] = s;
+            dst[1] = q;
+        }
+    }
+}
+
+template <int JN, int WNW, int KS>
+static int launch_cf(const ConvFArgs& a, int B, hipStream_t st) {
+    constexpr int PAD = KS / 2, NP = (8 + 2 * PAD) * (16 + 2 * PAD), NPP = (NP + 15) / 16 * 16;
+    constexpr int BN = WNW * JN * 16;
+    constexpr size_t lds = 2 * 4 * NPP * 16 + 2 * 2 * (BN / 16) * 1024;
+    if (a.Npad % BN) return LGEN_ERR_BAD_ARG;
+    dim3 grid(a.ntiles, a.Npad / BN, B);
+    hipLaunchKernelGGL((conv_fused_kernel<JN, WNW, KS>), grid, dim3(256), lds, st, a);
+    LGEN_CHECK_LAUNCH();
+    return 0;
+}
+
+// weight tile width (output channels per workgroup) this library uses for a given Cout: the host packs to it
+extern "C" int lgen_conv_fused_bn(int Cout) { return Cout >= 128 ? 128 : (Cout > 16 ? 64 : 16); }
+
+extern "C" int lgen_conv_fused(const float* x_nhwc, const float* gn_coef, int swish, const void* w_frag, const float* bias,
+                               const float* res, float* out, float* stats_partial, int B, int H, int W, int Cin, int Cout,
+                               int Npad, int ksize, int upsample, int out_nchw, void* stream) {
+    if ((ksize != 1 && ksize != 3) || Cin % 32 || H % 8 || W % 16 || Npad < Cout || (upsample && ((H | W) & 1)) ||
+        upsample < 0 || upsample > 1)
+        return LGEN_ERR_BAD_ARG;
+    if (B == 0) return 0;
+    const int bn = lgen_conv_fused_bn(Cout);
+    if (Npad % bn) return LGEN_ERR_BAD_ARG;
+    ConvFArgs a{x_nhwc, (const float2*)gn_coef, (const uint4*)w_frag, bias, res, out, stats_partial,
+                H, W, Cin, Cout, Npad, upsample, swish ? 1 : 0, out_nchw, W / 16, (H / 8) * (W / 16)};
+    hipStream_t st = (hipStream_t)stream;
+    if (bn == 128) return ksize == 3 ? launch_cf<4, 2, 3>(a, B, st) : launch_cf<4, 2, 1>(a, B, st);
+    if (bn == 64) return ksize == 3 ? launch_cf<4, 1, 3>(a, B, st) : launch_cf<4, 1, 1>(a, B, st);
+    return ksize == 3 ? launch_cf<1, 1, 3>(a, B, st) : launch_cf<1, 1, 1>(a, B, st);
+}
+
+// ---------------------------------------------------------------------------------------------
+// GroupNorm statistics -> per-channel (scale, shift): coef[b][c] = (rstd*gamma_c, beta_c - rstd*gamma_c*mean)
+// (vq_model.py:359-362, eps inside the sqrt, biased variance).  Input is either the per-tile partials written by
+// lgen_conv_fused (ntiles > 0: part[b][tile][C/4][2], fp32, combined here in fp64 in a fixed order) or finished
+// statistics stats[b][32][2] = (mean, rstd) from lgen_gn_stats (ntiles == 0).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ part, const float* __restrict__ stats,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float2* __restrict__ coef, int ntiles, int C, int Cq_stride,
+                                                         double count, float eps) {
+    const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const int gs = C >> 5;
+    float mean, rstd;
+    if (ntiles > 0) {
+        const int qpg = gs >> 2;  // 4-channel quads per group
+        double S = 0.0, Q = 0.0;
+        for (int i = lane; i < ntiles * qpg; i += 64) {
+            const int tile = i / qpg, qq = i - tile * qpg;
+            const float* p = part + (((size_t)b * ntiles + tile) * Cq_stride + g * qpg + qq) * 2;
+            S += (double)p[0];
+            Q += (double)p[1];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            S += __shfl_xor(S, o, 64);
+            Q += __shfl_xor(Q, o, 64);
+        }
+        const double m = S / count;
+        double var = Q / count - m * m;
+        var = var < 0.0 ? 0.0 : var;
+        mean = (float)m;
+        rstd = (float)(1.0 / sqrt(var + (double)eps));
+    } else {
+        mean = stats[((size_t)b * 32 + g) * 2];
+        rstd = stats[((size_t)b * 32 + g) * 2 + 1];
+    }
+    for (int c = g * gs + lane; c < (g + 1) * gs; c += 64) {
+        const float sc = rstd * gamma[c];
+        coef[(size_t)b * C + c] = make_float2(sc, beta[c] - sc * mean);
+    }
+}
+
+extern "C" int lgen_gn_finalize(const float* partial, const float* stats, const float* gamma, const float* beta, float* coef,
+                                int B, int C, int ntiles, int quad_stride, int hw, float eps, void* stream) {
+    if (C % 128 || (!partial && !stats) || (partial && ntiles < 1)) return LGEN_ERR_BAD_ARG;
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(32, B), dim3(64), 0, (hipStream_t)stream, partial, stats, gamma, beta,
+                       (float2*)coef, partial ? ntiles : 0, C, quad_stride, (double)hw * (C / 32), eps);
+    LGEN_CHECK_LAUNCH();
+    return 0;
+}

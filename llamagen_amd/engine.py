@@ -116,6 +116,7 @@ class DecodeEngine:
         self.V = cfg.vocab_size
         self.eps = cfg.norm_eps
         self.T = cfg.cls_token_num
+        self.model_type = model.model_type
         for n in (self.d, self.F):
             if n % 32:
                 raise NotImplementedError("model dims must be multiples of 32")
@@ -160,7 +161,12 @@ class DecodeEngine:
         self.cur_tok = z(mts * 16, dtype=torch.int32)
         self.seq = z(max_batch, S8 + 8, dtype=torch.int32)
         self.state = z(2, dtype=torch.int32)                 # [pos, step]
-        self.use_mask = False  # True once causal_mask deviates from pure causal (t2i emb_masks)
+        # The decode / prefill attention consults `causal_mask` (the tensor Transformer.setup_caches exposes as
+        # model.causal_mask, writable like the reference's, generate.py:154-163) whenever the model is t2i: a caller
+        # that folds emb_masks into it by hand and then drives __call__ gets the reference's result.  c2i models
+        # never edit the mask in the reference, so they keep the maskless (pure causal) kernels unless use_mask is set.
+        self.use_mask = False
+        self._force_causal = False  # whole-sequence `is_causal` forward (gpt.py:234) ignores causal_mask
         self._graphs = {}
         self._prof = None
         # RMSNorm folded into the consumer GEMMs (5 launches / layer instead of 7).  Pays off (-12 % step time,
@@ -272,7 +278,7 @@ class DecodeEngine:
         fuse = self.fuse_norm
         tq, to, t13, t2, th = (self._tiles("qkv", 3 * d, d), self._tiles("wo", d, d), self._tiles("w13", 2 * F, d),
                                self._tiles("w2", d, F), self._tiles("head", self.V, d))
-        pm = self.causal_mask if self.use_mask else None
+        pm = self._mask()
         ssq = self.ssq if fuse else None
 
         def hint(t):
@@ -319,6 +325,11 @@ class DecodeEngine:
                 x_in, nw = self.xnp, None
             hint(self.layers[0]["wqkv"])  # the next decode step starts there
             self.gemm(self.out_w, x_in, self.logits, M, mts, self.V, d, L.EPI_ROWS, th, norm_w=nw)
+
+    def _mask(self):
+        if self._force_causal:
+            return None
+        return self.causal_mask if (self.use_mask or self.model_type == "t2i") else None
 
     def _embed(self, table, idx, advance: bool = False):
         L.check(self.lib.lgen_embed_pack(L.ptr(table), L.ptr(idx), L.ptr(self.hp), L.ptr(self.ssq) if self.fuse_norm else 0,
@@ -391,7 +402,7 @@ class DecodeEngine:
         ws["hp"].copy_(pack_act(rows.contiguous(), mts).view_as(ws["hp"]))
         mt = min(mts, 4)
         tile = lambda N, K: (mt, 1, max(1, min(8, (K // self.kc) // 2)))
-        pm = self.causal_mask if self.use_mask else None
+        pm = self._mask()
         for i, w in enumerate(self.layers):
             L.check(lib.lgen_rmsnorm(L.ptr(ws["hp"]), L.ptr(w["an"]), L.ptr(ws["xn"]), mts, d, self.eps, dt, st), "rmsnorm")
             self.gemm(w["wqkv"], ws["xn"], ws["qkv"], R, mts, 3 * d, d, L.EPI_PACKED, tile(3 * d, d))
@@ -426,11 +437,11 @@ class DecodeEngine:
         cond = cond[:, : self.T]
         emb = torch.cat([cond, self.tok_emb[idx.long()]], dim=1)                  # [B, T + n, d]
         B2, S, d = emb.shape
-        masked, self.use_mask = self.use_mask, False  # this shape is `is_causal` in the reference (gpt.py:234), no emb_masks
+        self._force_causal = True  # this shape is `is_causal` in the reference (gpt.py:234), no emb_masks
         try:
             ws = self._run_sequence(emb)
         finally:
-            self.use_mask = masked
+            self._force_causal = False
         lib, st, dt, mts, R = self.lib, L.stream(), self.dt, ws["mts"], ws["R"]
         L.check(lib.lgen_rmsnorm(L.ptr(ws["hp"]), L.ptr(self.norm_w), L.ptr(ws["xn"]), mts, d, self.eps, dt, st), "rmsnorm")
         lg = torch.empty(mts * 16, self.V, dtype=self.dtype, device=self.dev)
@@ -479,6 +490,8 @@ class DecodeEngine:
         (llamagen_amd/pipeline.py); the int32 [B, N] result is the generator's return value."""
         N = max_new_tokens
         T = 1 if model.model_type == "c2i" else cond_combined.shape[1]
+        if T + N > self.S8 or T + N - 1 > self.freqs_cis.shape[0]:
+            raise IndexError(f"{T} + {N} tokens exceed the caches ({self.S8} slots) / RoPE table ({self.freqs_cis.shape[0]} rows)")
         self._prof = getattr(model, "_prof", None)
         self.state.zero_()
         if emb_masks is not None:  # generate.py:154-163: fold emb_masks into causal_mask, force the diagonal
@@ -508,7 +521,7 @@ class DecodeEngine:
         self._sample(B, sp)
         yield 0
         # ---- decode (generate.py:105-123): every step first advances (pos, step)
-        key = (B, N, self.use_mask, self.fuse_norm, tuple(sorted(self.tile_override.items())), sp["use_cfg"], sp["cfg_scale"],
+        key = (B, N, self._mask() is not None, self.fuse_norm, tuple(sorted(self.tile_override.items())), sp["use_cfg"], sp["cfg_scale"],
                sp["cfg_interval"], sp["temperature"], sp["top_k"], sp["top_p"], sp["sample_logits"],
                self.noise.data_ptr() if sampling else 0)
         use_graph = os.environ.get("LGEN_NO_GRAPH") is None and N > 3
@@ -553,6 +566,9 @@ class DecodeEngine:
             nb = idx.shape[0]
         if nb != self.B2:
             raise ValueError(f"batch {nb} != max_batch_size {self.B2} given to setup_caches")
+        for p in pos:  # the reference's index_put / freqs_cis[input_pos] raise IndexError (gpt.py:177-185, 356)
+            if not (0 <= p < self.S8 and p < self.freqs_cis.shape[0]):
+                raise IndexError(f"input_pos {p} outside the caches set up for {self.S8} slots / {self.freqs_cis.shape[0]} RoPE rows")
         for j, p in enumerate(pos):
             self.state[0] = p
             if embs is not None:

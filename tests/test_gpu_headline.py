@@ -1,0 +1,266 @@
+"""Parity of the kernels `bench.py` actually times (BASELINE config 2: GPT-L bf16, B2 = 64, fused-norm tiles,
+32 x 24 x 24 decode_code) and of the config 3-5 kernel shapes against the CPU oracle.
+
+The small-model tests of test_gpu_gpt.py pin the arithmetic; these pin the *instantiations*: the
+`gemm_normpre_kernel<BF16, 1, 4, EPI_QKV, 4>`, `<2, 4, EPI_SWIGLU, 4>`, `<2, 4, EPI_ROWS, 4>`,
+`gemm_kernel<BF16, 1, 1, EPI_RES, false, 6>` and `attn_decode_kernel<BF16, 8, 2, 2>` forms that the
+headline run replays, at late cache positions too.
+
+Tolerance (bf16 storage, stated here as the prompt asks): CFG-mixed logits within 4 (max) / 0.25 (mean)
+bf16 ulp of the largest logit -- the bar of test_forward_teacher_forced_bf16.  A bf16 model is not
+invariant to the GEMM accumulation order, so the same distance is also measured
+between two legitimate CPU evaluations of the oracle (fp32 vs fp64 accumulation in every nn.Linear); the HIP
+path must stay within max(fixed bar, 2 x that self-distance).  Measured on MI355X (gpurun_out/headline_parity.jsonl,
+quoted in DESIGN.md): HIP-vs-oracle is 1.0-1.3 x the oracle's own fp32-vs-fp64 distance at every step (GPT-L, 24
+layers: 4.2-7.4 ulp max / 0.68-0.97 ulp mean against 3.9-6.7 / 0.58-0.83).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import llamagen_oracle as O  # noqa: E402
+from tests.util import build_gpt_holder, build_vq_holder, oracle_cfg  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a real MI355X"
+    return torch.device("cuda:0")
+
+
+def _L():
+    from llamagen_amd import _lib
+    return _lib
+
+
+def _log(name, rec):
+    """Keep the measured distances (they back the tolerances quoted in DESIGN.md) when gpurun_out/ exists."""
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "headline_parity.jsonl"), "a") as f:
+            f.write(json.dumps(dict(test=name, **rec)) + "\n")
+
+
+class _Linear64:
+    """Context: O.linear with fp64 accumulation (a second legitimate evaluation order of the same model)."""
+
+    def __enter__(self):
+        self.orig = O.linear
+        O.linear = lambda x, w, dt: O._rnd((x.double() @ w.double().t()).float(), dt)
+
+    def __exit__(self, *a):
+        O.linear = self.orig
+
+
+def _fill_caches(oracle, eng, pos, hd, seed):
+    """Same pseudo-random storage-dtype K/V in slots [0, pos) of every layer of the oracle and the engine."""
+    g = torch.Generator().manual_seed(seed)
+    B2, H, S8 = oracle.k_cache[0].shape[:3]
+    kb = (torch.randn(B2, H, S8, hd, generator=g) * 0.6).to(oracle.dt)
+    vb = (torch.randn(B2, H, S8, hd, generator=g) * 0.6).to(oracle.dt)
+    kd, vd = kb.to(eng.dev), vb.to(eng.dev)
+    for li in range(len(oracle.k_cache)):
+        sh = (li * 37) % S8  # a different arrangement per layer, one random draw in total
+        oracle.k_cache[li][:, :, :pos] = torch.roll(kb, sh, dims=2)[:, :, :pos].float()
+        oracle.v_cache[li][:, :, :pos] = torch.roll(vb, sh, dims=2)[:, :, :pos].float()
+        eng.k_cache[li][:, :, :pos, :hd] = torch.roll(kd, sh, dims=2)[:, :, :pos]
+        eng.v_cache[li][:, :, :pos, :hd] = torch.roll(vd, sh, dims=2)[:, :, :pos]
+
+
+def _teacher_forced(case, B, cfg_scale, early, late, cond, emb_masks=None, T=1):
+    """Runs prefill + `early` decode positions (+ `late` positions on injected cache contents) through
+    Transformer.__call__ on the GPU and through two evaluations of the oracle; returns per-step distances."""
+    dev = _dev()
+    m, sd = build_gpt_holder(case)
+    dt = torch.bfloat16
+    m = m.to(device=dev, dtype=dt)
+    cfgo = oracle_cfg(case)
+    N = case["kwargs"]["block_size"]
+    V = case["kwargs"]["vocab_size"]
+    B2 = 2 * B
+    if cfgo.model_type == "c2i":
+        cond_c = torch.cat([cond, torch.ones_like(cond) * cfgo.num_classes])
+        cond_dev = cond_c.to(dev)
+    else:
+        cond_c = torch.cat([cond, torch.zeros_like(cond) + sd["cls_embedding.uncond_embedding"]])
+        cond_dev = cond_c.to(dev).to(dt)
+    oracles = [O.GPTOracle(cfgo, sd, dt), O.GPTOracle(cfgo, sd, dt)]
+    for o in oracles:
+        o.setup_caches(B2, T + N)
+    m.setup_caches(B2, T + N, dt)
+    if emb_masks is not None:  # generate.py:154-163, written through the drop-in API (model.causal_mask)
+        em = torch.cat([emb_masks, emb_masks])
+        for o in oracles:
+            cm = o.causal_mask
+            cm[:, :, :T] = cm[:, :, :T] & (em.unsqueeze(1) != 0)
+            o.causal_mask = cm | torch.eye(cm.size(1), dtype=torch.bool)
+        cmd = m.causal_mask
+        cmd[:, :, :T] = cmd[:, :, :T] & (em.to(dev).unsqueeze(1) != 0)
+        cmd |= torch.eye(cmd.size(1), dtype=torch.bool, device=dev)
+    g = torch.Generator().manual_seed(77)
+    steps = []   # (label, idx or None, cond or None, input_pos)
+    steps.append(("prefill", None, True, torch.arange(0, T)))
+    for i in range(early):
+        steps.append((f"pos{T + i}", torch.randint(0, V, (B, 1), generator=g), None, torch.tensor([T + i])))
+    for p in late:
+        steps.append((f"late{p}", torch.randint(0, V, (B, 1), generator=g), None, torch.tensor([p])))
+    out = []
+    hd = cfgo.head_dim
+    for label, tok, is_cond, ipos in steps:
+        if label.startswith("late"):
+            p = int(ipos[0])
+            for k, o in enumerate(oracles):
+                _fill_caches(o, m._engine, p, hd, seed=1000 + p)
+        refs = []
+        for k, o in enumerate(oracles):
+            x = None if tok is None else torch.cat([tok, tok])
+            if k == 1:
+                with _Linear64():
+                    refs.append(o.forward(x, cond_c if is_cond else None, ipos)[:, -1])
+            else:
+                refs.append(o.forward(x, cond_c if is_cond else None, ipos)[:, -1])
+        if is_cond:
+            lg, _ = m(None, cond_dev, ipos.to(dev))
+        else:
+            lg, _ = m(torch.cat([tok, tok]).to(dev), None, ipos.to(dev).to(torch.int))
+        got = O.cfg_mix(lg[:, -1].float().cpu(), cfg_scale)
+        r0, r1 = O.cfg_mix(refs[0], cfg_scale), O.cfg_mix(refs[1], cfg_scale)
+        ulp = r0.abs().max().item() * 2.0 ** -8
+        e, s = (got - r0).abs(), (r1 - r0).abs()
+        out.append(dict(step=label, ulp=ulp, err_max=e.max().item() / ulp, err_mean=e.mean().item() / ulp,
+                        self_max=s.max().item() / ulp, self_mean=s.mean().item() / ulp,
+                        argmax_agree=float((got.argmax(-1) == r0.argmax(-1)).float().mean())))
+    return out, m
+
+
+def _check(name, recs):
+    for r in recs:
+        _log(name, r)
+    for r in recs:
+        assert r["err_max"] <= max(4.0, 2.0 * r["self_max"]), (name, r)
+        assert r["err_mean"] <= max(0.25, 2.0 * r["self_mean"]), (name, r)
+
+
+def test_config2_gptl_bf16_b64_logits_vs_oracle():
+    """BASELINE config 2 instantiations: GPT-L (24 layers, d 1024, 16 heads), bf16, B = 32 -> 64 rows, S8 = 584:
+    prefill, positions 1..6, and positions 299 / 574 on injected cache contents."""
+    case = dict(registry="GPT-L", kwargs=dict(vocab_size=16384, block_size=576, num_classes=1000, cls_token_num=1,
+                                              model_type="c2i"), wseed=21, lin_std=0.02)
+    B = 32
+    cond = torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(3))
+    recs, m = _teacher_forced(case, B, 4.0, early=6, late=[299, 574], cond=cond)
+    e = m._engine
+    assert e.fuse_norm and e.MTs == 4 and e.S8 == 584
+    assert e._tiles("qkv", 3 * e.d, e.d) == (1, 4, 8) and e._tiles("w13", 2 * e.F, e.d) == (2, 4, 8)  # what bench.py replays
+    _check("config2_gptl_b64", recs)
+
+
+@pytest.mark.parametrize("d,H", [(1024, 16), (1280, 20), (1536, 24), (768, 12)])
+@pytest.mark.parametrize("pos", [0, 301])
+def test_qkv_fused_norm_rope_append_vs_oracle(d, H, pos):
+    """lgen_gemm_qkv_rope WITH the fused RMSNorm (norm_w / ssq_in), 64 rows, tiles (1, 4, 8): CPW 3 / 4 / 5 / 6 =
+    GPT-B / L / XL / XXL, vs oracle rms_norm -> linear -> apply_rotary_emb -> KVCache.update."""
+    from llamagen_amd.engine import pack_act, pack_weight, precompute_freqs_cis_2d
+    from tests.test_gpu_gpt import _close, _rand
+    L, dev = _L(), _dev()
+    lib = L.lib()
+    dt, M, hd, grid = torch.bfloat16, 64, 64, 24
+    S8 = O.find_multiple(1 + grid * grid, 8)
+    mts = 4
+    x = _rand((M, d), dt, 41, 1.3)
+    w = _rand((3 * d, d), dt, 42, 0.03)
+    nw = (1 + 0.1 * _rand((d,), torch.float32, 43)).to(dt)
+    freqs = precompute_freqs_cis_2d(grid, hd, 10000.0, 1)
+    xp, wp, nw_d, fr_d = pack_act(x.to(dev), mts), pack_weight(w.to(dev)), nw.to(dev), freqs.to(dev)
+    ssq = torch.full((d // 32, mts * 16), float("nan"), device=dev)
+    L.check(lib.lgen_ssq_pack(L.ptr(xp), L.ptr(ssq), mts, d, L.BF16, L.stream()), "ssq_pack")
+    kc = torch.zeros(M, H, S8, 64, dtype=dt, device=dev)
+    vc = torch.zeros(M, H, S8, 64, dtype=dt, device=dev)
+    q = torch.zeros(mts * 16, H, 64, dtype=dt, device=dev)
+    state = torch.tensor([pos, 0], dtype=torch.int32, device=dev)
+    L.check(lib.lgen_gemm_qkv_rope(L.ptr(wp), L.ptr(xp), L.ptr(q), L.ptr(kc), L.ptr(vc), L.ptr(fr_d), L.ptr(state), M, mts, d, H,
+                                   hd, 64, S8, 0, L.BF16, 1, 4, 8, L.ptr(nw_d), L.ptr(ssq), d // 32, 1e-5, L.stream()), "qkv fused")
+    xn = O.rms_norm(x.float(), nw, 1e-5, dt)
+    qkv = O.linear(xn, w.float(), dt)
+    xq, xk, xv = qkv.split([d, d, d], dim=-1)
+    fr = freqs[pos:pos + 1]
+    xq = O.apply_rotary_emb(xq.reshape(M, 1, H, hd), fr, dt)[:, 0]
+    xk = O.apply_rotary_emb(xk.reshape(M, 1, H, hd), fr, dt)[:, 0]
+    _close(q[:M], xq, dt, "q", frac_ulp1=0.05, mag=qkv[:, :d].reshape(M, H, hd))
+    _close(kc[:, :, pos], xk, dt, "k row", frac_ulp1=0.05, mag=qkv[:, d:2 * d].reshape(M, H, hd))
+    _close(vc[:, :, pos], xv.reshape(M, H, hd), dt, "v row", frac_ulp1=0.05)
+    kc[:, :, pos] = 0
+    vc[:, :, pos] = 0
+    assert not kc.any() and not vc.any()  # nothing but slot `pos` was written
+
+
+def test_decode_code_batch32_384px_vs_oracle():
+    """The decode_code() shape of the bench (32 x 24 x 24 codes -> 32 x 3 x 384 x 384): three of the images against
+    the oracle decoder (GroupNorm statistics are per image, so the oracle decodes them one by one)."""
+    from tests.cases import VQ_CASES
+    m, sd = build_vq_holder(VQ_CASES["vq16_4x4"])
+    dev = _dev()
+    m = m.to(dev)
+    codes = torch.randint(0, 16384, (32, 576), generator=torch.Generator().manual_seed(8))
+    img = m.decode_code(codes.to(dev), [32, 8, 24, 24])
+    assert tuple(img.shape) == (32, 3, 384, 384) and torch.isfinite(img).all()
+    worst = 0.0
+    for b in (0, 13, 31):
+        ref = O.vq_decode_code(sd, codes[b:b + 1], [1, 8, 24, 24])
+        worst = max(worst, (img[b:b + 1].cpu() - ref).abs().max().item())
+    _log("decode_code_b32", dict(max_abs_err=worst))
+    assert worst < 1e-3, worst  # north_star: decoded pixels within 1e-3 abs
+
+
+def test_config4_gpt3b_shapes_bf16_vs_oracle():
+    """BASELINE config 4 kernel shapes: GPT-3B widths (d 3200, 32 heads, head_dim 100 -> padded 128, F 8704),
+    B = 64 -> 128 rows (MTs 8), 384 px (S8 584); depth cut to 4 layers so that the oracle finishes in seconds."""
+    kw = dict(n_layer=4, n_head=32, dim=3200, vocab_size=16384, block_size=576, num_classes=1000, cls_token_num=1,
+              model_type="c2i")
+    case = dict(kwargs=kw, wseed=22, lin_std=0.02)
+    B = 64
+    cond = torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(4))
+    recs, m = _teacher_forced(case, B, 4.0, early=3, late=[420], cond=cond)
+    e = m._engine
+    assert e.hd == 100 and e.hdp == 128 and e.MTs == 8 and e.F == 8704
+    _check("config4_gpt3b_shapes", recs)
+
+
+def test_config5_gptxl_t2i_shapes_bf16_vs_oracle():
+    """BASELINE config 5 kernel shapes: GPT-XL widths (d 1280, 20 heads, F 3584), t2i with T = 120 caption tokens
+    (caption_dim 2048, left-padded emb_masks folded into causal_mask through the drop-in API), 512 px
+    (block_size 1024, S8 1144), B = 16 -> 32 rows, cfg 7.5; depth cut to 4 layers."""
+    kw = dict(n_layer=4, n_head=20, dim=1280, vocab_size=16384, block_size=1024, cls_token_num=120, caption_dim=2048,
+              model_type="t2i")
+    case = dict(kwargs=kw, wseed=23, lin_std=0.02)
+    B, T = 16, 120
+    g = torch.Generator().manual_seed(5)
+    emb = torch.randn(B, T, 2048, generator=g)
+    lens = torch.randint(5, T + 1, (B,), generator=g)
+    mask = torch.zeros(B, T, dtype=torch.int64)
+    for b in range(B):
+        mask[b, T - int(lens[b]):] = 1
+    emb = (emb * mask[:, :, None]).to(torch.bfloat16).float()
+    recs, m = _teacher_forced(case, B, 7.5, early=3, late=[700, 1142], cond=emb, emb_masks=mask, T=T)
+    e = m._engine
+    assert e.S8 == 1144 and e.T == 120 and e.MTs == 2
+    _check("config5_gptxl_t2i_shapes", recs)
+
+
+def test_config3_gptxxl_shapes_bf16_vs_oracle():
+    """BASELINE config 3 per-GPU kernel shapes: GPT-XXL widths (d 1536, 24 heads, F 4096; fused-norm CPW 6), B = 32 -> 64
+    rows, 384 px; depth cut to 4 layers."""
+    kw = dict(n_layer=4, n_head=24, dim=1536, vocab_size=16384, block_size=576, num_classes=1000, cls_token_num=1,
+              model_type="c2i")
+    case = dict(kwargs=kw, wseed=24, lin_std=0.02)
+    B = 32
+    cond = torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(6))
+    recs, m = _teacher_forced(case, B, 4.0, early=3, late=[575], cond=cond)
+    assert m._engine.fuse_norm
+    _check("config3_gptxxl_shapes", recs)

@@ -162,6 +162,26 @@ int lgen_conv_igemm(const void* a_hi, const void* a_lo, const void* w_hi, const 
                     const float* res, float* out, int B, int H, int W, int Cin, int Cout, int Npad, int ksize,
                     int upsample, int out_nchw, long long w_bstride, float alpha, void* stream);
 
+/* Fused decoder convolution (vq_model.py:299-314 ResnetBlock body, :374-378 Upsample, :190-192 norm_out/swish/conv_out):
+ * out = conv_{ksize x ksize, pad ksize/2}( swish?( x * scale_c + shift_c ) ) + bias (+ res), with the GroupNorm-apply
+ * (gn_coef [B][Cin][2] = (scale, shift) from lgen_gn_finalize, or NULL), the activation and the hi/lo bf16 split done
+ * on the tile load (x is read once, as fp32 NHWC [B][H>>upsample][W>>upsample][Cin]), the 3x3 taps served from an
+ * LDS-resident halo tile, and -- stats_partial != NULL -- the next GroupNorm's per-(8x16 tile, 4-channel quad)
+ * (sum, sumsq) of the stored output written to stats_partial [B][(H/8)*(W/16)][Npad/4][2].  upsample = 1 folds
+ * F.interpolate(2.0, nearest).  w_frag: hi/lo bf16 weights in MFMA fragment order
+ * [Npad/BN][Cin/32][ksize^2][2][BN/16][64 lanes][8], BN = lgen_conv_fused_bn(Cout).  Needs H % 8 == 0, W % 16 == 0,
+ * Cin % 32 == 0 (other shapes: lgen_gn_stats + lgen_gn_swish_split + lgen_conv_igemm). */
+int lgen_conv_fused_bn(int Cout);
+int lgen_conv_fused(const float* x_nhwc, const float* gn_coef, int swish, const void* w_frag, const float* bias,
+                    const float* res, float* out, float* stats_partial, int B, int H, int W, int Cin, int Cout, int Npad,
+                    int ksize, int upsample, int out_nchw, void* stream);
+
+/* GroupNorm(32, C, eps) statistics -> per-channel (scale, shift) = (rstd*gamma, beta - rstd*gamma*mean), coef [B][C][2].
+ * Source: partial != NULL: the tile partials of lgen_conv_fused ([B][ntiles][quad_stride][2], combined in fp64 in a
+ * fixed order; hw = pixels per image); else stats [B][32][2] = (mean, rstd) from lgen_gn_stats. */
+int lgen_gn_finalize(const float* partial, const float* stats, const float* gamma, const float* beta, float* coef, int B,
+                     int C, int ntiles, int quad_stride, int hw, float eps, void* stream);
+
 /* ---- post-processing of decoded samples (autoregressive/sample/sample_c2i_ddp.py:141-143) ------------- */
 
 /* F.interpolate(x, size=(Ho, Wo), mode='bicubic') (align_corners=False, A = -0.75): fp32 NCHW [BC][Hi][Wi] -> [BC][Ho][Wo]. */

@@ -109,7 +109,8 @@ __global__ __launch_bounds__(256, 2) void conv_fused_kernel(ConvFArgs a) {
         }                                                                                           \
     }
     auto store_halo = [&]() {
-        const float* cff = (const float*)cf;
+        const float sc[8] = {cf[0].x, cf[0].z, cf[1].x, cf[1].z, cf[2].x, cf[2].z, cf[3].x, cf[3].z};
+        const float sh[8] = {cf[0].y, cf[0].w, cf[1].y, cf[1].w, cf[2].y, cf[2].w, cf[3].y, cf[3].w};
 #pragma unroll
         for (int i = 0; i < ITER; ++i) {
             const int it = t + i * 256;
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void conv_fused_kernel(ConvFArgs a) {
                 float f[8] = {raw[i][0].x, raw[i][0].y, raw[i][0].z, raw[i][0].w, raw[i][1].x, raw[i][1].y, raw[i][1].z, raw[i][1].w};
                 if (a.coef) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) f[e] = fmaf(f[e], cff[2 * e], cff[2 * e + 1]);
+                    for (int e = 0; e < 8; ++e) f[e] = fmaf(f[e], sc[e], sh[e]);
                 }
                 if (a.swish) {
 #pragma unroll
@@ -132,23 +133,31 @@ __global__ __launch_bounds__(256, 2) void conv_fused_kernel(ConvFArgs a) {
             }
         }
     };
-    uint4 wreg[W_IT];
     const uint4* wbase = a.w + (size_t)nb * nkc * TAPS * (WT / 16);
-#define CF_GLOAD_W(step_)                                                                           \
-    {                                                                                               \
-        const int st_ = (step_) < nsteps ? (step_) : nsteps - 1;                                    \
-        _Pragma("unroll") for (int i = 0; i < W_IT; ++i) {                                          \
-            const int idx = t + i * 256;                                                            \
-            wreg[i] = wbase[(size_t)st_ * (WT / 16) + (idx < WT / 16 ? idx : 0)];                   \
-        }                                                                                           \
-    }
-#define CF_LSTORE_W(buf_)                                                                           \
-    {                                                                                               \
-        _Pragma("unroll") for (int i = 0; i < W_IT; ++i) {                                          \
-            const int idx = t + i * 256;                                                            \
-            if (W_IT * 256 == WT / 16 || idx < WT / 16) *(uint4*)(sW + (buf_) * WT + idx * 16) = wreg[i]; \
-        }                                                                                           \
-    }
+    uint4 wr0 = make_uint4(0, 0, 0, 0), wr1 = wr0, wr2 = wr0, wr3 = wr0;  // W_IT <= 4 staging registers (scalars: an
+    // indexed array here ends up in scratch memory -- hipcc does not promote it across the two loop levels)
+    auto gload_w = [&](int step_) {
+        const int st_ = step_ < nsteps ? step_ : nsteps - 1;  // tail: harmless re-load
+        const uint4* src = wbase + (size_t)st_ * (WT / 16);
+        if constexpr (W_IT == 4) {
+            wr0 = src[t]; wr1 = src[t + 256]; wr2 = src[t + 512]; wr3 = src[t + 768];
+        } else if constexpr (W_IT == 2) {
+            wr0 = src[t]; wr1 = src[t + 256];
+        } else {
+            wr0 = src[t < WT / 16 ? t : 0];
+        }
+    };
+    auto lstore_w = [&](int buf_) {
+        unsigned char* dst = sW + buf_ * WT + t * 16;
+        if constexpr (W_IT == 4) {
+            *(uint4*)(dst) = wr0; *(uint4*)(dst + 4096) = wr1; *(uint4*)(dst + 8192) = wr2; *(uint4*)(dst + 12288) = wr3;
+        } else if constexpr (W_IT == 2) {
+            *(uint4*)(dst) = wr0; *(uint4*)(dst + 4096) = wr1;
+        } else {
+            if (t < WT / 16) *(uint4*)(dst) = wr0;
+        }
+    };
+    static_assert(W_IT == 4 || W_IT == 2 || (W_IT == 1 && WT / 16 <= 256), "weight tile staging shape");
 
     f32x4_t acc[JN][JM];
 #pragma unroll
@@ -180,26 +189,24 @@ __global__ __launch_bounds__(256, 2) void conv_fused_kernel(ConvFArgs a) {
         }
     };
 
+    gload_w(0);
     CF_GLOAD_HALO(0);
-    CF_GLOAD_W(0);
+    lstore_w(0);
     for (int kc = 0; kc < nkc; ++kc) {
         // every wave has finished reading the previous chunk's halo (barrier at the end of its last tap)
         store_halo();
-        if (kc == 0) CF_LSTORE_W(0);
         __syncthreads();
         if (kc + 1 < nkc) CF_GLOAD_HALO(kc + 1);  // lands during the taps of this chunk
-#pragma unroll 1
+
         for (int tap = 0; tap < TAPS; ++tap) {
             const int s = kc * TAPS + tap;
-            CF_GLOAD_W(s + 1);
+            gload_w(s + 1);
             compute(s & 1, tap);
-            CF_LSTORE_W((s + 1) & 1);
+            lstore_w((s + 1) & 1);
             __syncthreads();
         }
     }
 #undef CF_GLOAD_HALO
-#undef CF_GLOAD_W
-#undef CF_LSTORE_W
 
     // epilogue: lane holds channels n = n0 + g*4 + {0..3} of pixel (y0 + row, x0 + fr)
     const size_t HW = (size_t)a.H * a.W;

@@ -39,6 +39,24 @@ def to_uint8_hwc(samples: torch.Tensor, image_size_eval: Optional[int] = None) -
     return out
 
 
+def save_image_grid(samples: torch.Tensor, path: str, nrow: int = 4, padding: int = 2) -> str:
+    """What sample_c2i.py:95 does with torchvision's `save_image(samples, path, nrow=4, normalize=True, value_range=(-1, 1))`:
+    [-1, 1] -> [0, 1] clamp, a grid `nrow` images wide with `padding` black pixels between them, PNG via PIL.  The
+    clamp / scale / uint8 conversion of every image runs in the HIP library (lgen_to_uint8_hwc computes clamp(127.5 x + 128),
+    within half a grey level of torchvision's round(255 (x + 1) / 2)); only the paste and the file write are host work."""
+    from PIL import Image
+    u8 = to_uint8_hwc(samples).cpu().numpy()
+    n, h, w, c = u8.shape
+    cols = min(nrow, n)
+    rows = (n + cols - 1) // cols
+    grid = np.zeros((rows * (h + padding) + padding, cols * (w + padding) + padding, c), dtype=np.uint8)
+    for i in range(n):
+        y, x = (i // cols) * (h + padding) + padding, (i % cols) * (w + padding) + padding
+        grid[y:y + h, x:x + w] = u8[i]
+    Image.fromarray(grid).save(path)
+    return path
+
+
 def save_npz(samples_uint8: torch.Tensor, npz_path: str, num: Optional[int] = None) -> str:
     """create_npz_from_sample_folder (sample_c2i_ddp.py:21-35) without the PNG detour: [N, H, W, 3] uint8 ->
     `arr_0` of an .npz, exactly what evaluations/c2i/evaluator.py reads."""

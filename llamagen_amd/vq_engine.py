@@ -9,6 +9,8 @@ re-layout only.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib as L
@@ -34,6 +36,16 @@ class _ConvW:
         self.hi, self.lo = _split_planes(wt)
         self.bias = conv.bias.detach().float().contiguous()
         self.cin, self.cout, self.npad, self.k = cpad, cout, npad, k
+        # fragment-packed copy for lgen_conv_fused: [Npad/BN][Cin/32][taps][hi|lo][BN/16][4 g][16 r][8] -- one 1 KiB
+        # block is one MFMA A fragment (lane = g*16 + r holds output channel r, input channels g*8..g*8+7)
+        bn = 128 if cout >= 128 else (64 if cout > 16 else 16)
+        self.fnpad = (cout + bn - 1) // bn * bn
+        wf = torch.zeros(k * k, self.fnpad, cpad, device=w.device)
+        wf[:, :cout, :cin] = wt[:, :cout, :cin]
+        fh, fl = _split_planes(wf)
+        pk = lambda q: q.view(k * k, self.fnpad // bn, bn // 16, 16, cpad // 32, 4, 8).permute(1, 4, 0, 2, 5, 3, 6)
+        self.frag = torch.stack([pk(fh), pk(fl)], dim=3).contiguous()  # [nb][kc][tap][plane][j][g][r][8]
+        self.bn = bn
 
 
 class _GNW:
@@ -43,13 +55,22 @@ class _GNW:
         self.eps = gn.eps
 
 
+class _Act:
+    """An NHWC fp32 activation plus, when a fused conv produced it, the per-tile (sum, sumsq) partials of its values
+    (the next GroupNorm's statistics without another pass over the tensor)."""
+    __slots__ = ("t", "part", "ntiles", "qstride")
+
+    def __init__(self, t, part=None, ntiles=0, qstride=0):
+        self.t, self.part, self.ntiles, self.qstride = t, part, ntiles, qstride
+
+
 class VQEngine:
     def __init__(self, model):
         self.lib = L.lib()
-        import os
         if os.environ.get("LGEN_VQ_NT") is not None:  # tuning knob, see lgen_set_vq_nt in lgen.h
             self.lib.lgen_set_vq_nt(int(os.environ["LGEN_VQ_NT"]))
         self.dev = model.post_quant_conv.weight.device
+        self.fused = os.environ.get("LGEN_VQ_FUSED", "1") != "0"  # lgen_conv_fused where the shape allows it
         cfg = model.config
         self.n_e, self.e_dim, self.l2 = cfg.codebook_size, cfg.codebook_embed_dim, cfg.codebook_l2_norm
         self._sig_v = self._sig(model)
@@ -115,6 +136,42 @@ class VQEngine:
                                          1 if out_nchw else 0, 0, 1.0, L.stream()), "conv_igemm")
         return out
 
+    # ---- fused path (lgen_conv_fused): GroupNorm-apply / swish / split on the tile load, statistics in the epilogue --------
+    @staticmethod
+    def _fusable(H, W):
+        return H % 8 == 0 and W % 16 == 0
+
+    def _coef(self, x: "_Act", gn: _GNW, B, hw, C):
+        """Per-channel (scale, shift) of GroupNorm `gn` on activation x: from the producer's tile partials when it has them,
+        else from a statistics pass."""
+        coef = torch.empty(B * C * 2, dtype=torch.float32, device=self.dev)
+        if x.part is not None:
+            L.check(self.lib.lgen_gn_finalize(L.ptr(x.part), 0, L.ptr(gn.gamma), L.ptr(gn.beta), L.ptr(coef), B, C, x.ntiles,
+                                              x.qstride, hw, gn.eps, L.stream()), "gn_finalize")
+        else:
+            st = self._stats(x.t, B, hw, C, gn.eps)
+            L.check(self.lib.lgen_gn_finalize(0, L.ptr(st), L.ptr(gn.gamma), L.ptr(gn.beta), L.ptr(coef), B, C, 0, 0, hw, gn.eps,
+                                              L.stream()), "gn_finalize")
+        return coef
+
+    def _convf(self, x: "_Act", cw: _ConvW, B, H, W, coef=None, swish=False, upsample=False, res=None, out_nchw=False,
+               want_part=True) -> "_Act":
+        """H, W = OUTPUT size.  x.t is fp32 NHWC [B][H>>ups][W>>ups][cin]."""
+        out = torch.empty(B * H * W * cw.cout, dtype=torch.float32, device=self.dev)
+        ntiles = (H // 8) * (W // 16)
+        part = torch.empty(B * ntiles * (cw.fnpad // 4) * 2, dtype=torch.float32, device=self.dev) if want_part else None
+        L.check(self.lib.lgen_conv_fused(L.ptr(x.t), L.ptr(coef), 1 if swish else 0, L.ptr(cw.frag), L.ptr(cw.bias),
+                                         L.ptr(res.t if isinstance(res, _Act) else res), L.ptr(out), L.ptr(part), B, H, W, cw.cin,
+                                         cw.cout, cw.fnpad, cw.k, 1 if upsample else 0, 1 if out_nchw else 0, L.stream()),
+                "conv_fused")
+        return _Act(out, part, ntiles, cw.fnpad // 4)
+
+    def _res_fused(self, x: "_Act", p, B, H, W) -> "_Act":
+        hw, cin = H * W, p["c1"].cin
+        h = self._convf(x, p["c1"], B, H, W, coef=self._coef(x, p["n1"], B, hw, cin), swish=True)
+        skip = x if p["nin"] is None else self._convf(x, p["nin"], B, H, W, want_part=False)
+        return self._convf(h, p["c2"], B, H, W, coef=self._coef(h, p["n2"], B, hw, p["c1"].cout), swish=True, res=skip)
+
     def _gemm_nt(self, a_planes, b_planes, B, M, N, K, npad, alpha):
         """out[b] = alpha * A[b] (M x K) . Bm[b] (N x K)^T, batched, via the igemm kernel (1x1, W = 1)."""
         out = torch.empty(B * M * N, dtype=torch.float32, device=self.dev)
@@ -124,6 +181,10 @@ class VQEngine:
 
     # ---- blocks (vq_model.py:299-314, 327-351) ----------------------------------------------
     def _res(self, x, p, B, H, W):
+        if isinstance(x, _Act):
+            if self.fused and self._fusable(H, W):
+                return self._res_fused(x, p, B, H, W)
+            return _Act(self._res(x.t, p, B, H, W))
         hw, cin = H * W, p["c1"].cin
         h = self._conv(self._split(x, B, hw, cin, p["n1"], True), p["c1"], B, H, W)
         cmid = p["c1"].cout
@@ -131,6 +192,8 @@ class VQEngine:
         return self._conv(self._split(h, B, hw, cmid, p["n2"], True), p["c2"], B, H, W, res=skip)
 
     def _attn(self, x, p, B, H, W):
+        if isinstance(x, _Act):
+            return _Act(self._attn(x.t, p, B, H, W))
         hw, c = H * W, p["q"].cin
         hn = self._split(x, B, hw, c, p["n"], False)
         q = self._conv(hn, p["q"], B, H, W)
@@ -180,7 +243,10 @@ class VQEngine:
 
     def _decoder(self, z, B, H, W):
         """Decoder.forward, vq_model.py:173-194; z NHWC [B*H*W*z_channels]."""
-        x = self._conv(self._split(z, B, H * W, self.zc), self.conv_in, B, H, W)
+        if self.fused and self._fusable(H, W):
+            x = self._convf(_Act(z), self.conv_in, B, H, W)
+        else:
+            x = _Act(self._conv(self._split(z, B, H * W, self.zc), self.conv_in, B, H, W))
         x = self._res(x, self.mid[0], B, H, W)
         x = self._attn(x, self.mid[1], B, H, W)
         x = self._res(x, self.mid[2], B, H, W)
@@ -191,10 +257,17 @@ class VQEngine:
                     x = self._attn(x, lv["attn"][bi], B, H, W)
             if lv["up"] is not None:
                 c = lv["up"].cin
-                x = self._conv(self._split(x, B, H * W, c), lv["up"], B, 2 * H, 2 * W, upsample=True)
+                if self.fused and self._fusable(2 * H, 2 * W):
+                    x = self._convf(x, lv["up"], B, 2 * H, 2 * W, upsample=True)
+                else:
+                    x = _Act(self._conv(self._split(x.t, B, H * W, c), lv["up"], B, 2 * H, 2 * W, upsample=True))
                 H, W = 2 * H, 2 * W
         c = self.conv_out.cin
-        out = self._conv(self._split(x, B, H * W, c, self.norm_out, True), self.conv_out, B, H, W, out_nchw=True)
+        if self.fused and self._fusable(H, W):
+            out = self._convf(x, self.conv_out, B, H, W, coef=self._coef(x, self.norm_out, B, H * W, c), swish=True,
+                              out_nchw=True, want_part=False).t
+        else:
+            out = self._conv(self._split(x.t, B, H * W, c, self.norm_out, True), self.conv_out, B, H, W, out_nchw=True)
         return out.view(B, self.conv_out.cout, H, W)
 
     def argmin(self, z):

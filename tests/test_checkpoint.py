@@ -1,0 +1,47 @@
+"""CPU-only: the checkpoint sniffing of the reference's drivers (sample_c2i.py:48-61) on the drop-in modules."""
+import pytest
+import torch
+
+from llamagen_amd.checkpoint import load_gpt_checkpoint, load_vq_checkpoint, pick_state_dict
+from llamagen_amd.gpt import ModelArgs, Transformer
+from llamagen_amd.testing import synth_for_module
+from llamagen_amd.vq_model import VQ_models
+
+KW = dict(n_layer=1, n_head=2, dim=64, vocab_size=64, block_size=4, num_classes=3, cls_token_num=1, model_type="c2i")
+
+
+@pytest.mark.parametrize("wrap", ["model", "module", "state_dict", "fsdp"])
+def test_gpt_checkpoint_layouts(wrap, tmp_path):
+    m = Transformer(ModelArgs(**KW))
+    sd = synth_for_module(m, seed=4)
+    sd_disk = dict(sd)
+    sd_disk["freqs_cis"] = torch.zeros(5, 16, 2)                       # stray buffer of older reference checkpoints
+    sd_disk["layers.0.attention.kv_cache.k_cache"] = torch.zeros(1)    # never a parameter here
+    ck = sd_disk if wrap == "fsdp" else {wrap: sd_disk, "steps": 7}
+    path = tmp_path / "gpt.pt"
+    torch.save(ck, path)
+    missing, unexpected = load_gpt_checkpoint(m, str(path), from_fsdp=(wrap == "fsdp"))
+    assert missing == [] and unexpected == []
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+
+
+def test_gpt_checkpoint_precedence_and_errors():
+    a, b = {"x": torch.ones(1)}, {"x": torch.zeros(1)}
+    assert pick_state_dict({"model": a, "module": b})["x"].item() == 1.0   # "model" wins, like the reference's elif chain
+    assert pick_state_dict({"module": b, "state_dict": a})["x"].item() == 0.0
+    with pytest.raises(Exception, match="from-fsdp"):
+        pick_state_dict({"weights": a})
+    assert pick_state_dict(a, from_fsdp=True)["x"].item() == 1.0
+
+
+def test_vq_checkpoint_is_strict(tmp_path):
+    vq = VQ_models["VQ-16"](codebook_size=64, codebook_embed_dim=8)
+    sd = synth_for_module(vq, seed=2)
+    torch.save({"model": sd, "ema": {}}, tmp_path / "vq.pt")
+    load_vq_checkpoint(vq, str(tmp_path / "vq.pt"))
+    assert torch.equal(vq.state_dict()["quantize.embedding.weight"], sd["quantize.embedding.weight"])
+    bad = dict(sd)
+    bad.pop("post_quant_conv.bias")
+    with pytest.raises(RuntimeError):
+        load_vq_checkpoint(vq, {"model": bad})

@@ -255,3 +255,95 @@ def test_extract_codes_flip_augmentation():
     np.testing.assert_array_equal(codes[:, 0].reshape(-1).cpu().numpy(), gold["indices"])
     _, idx_f, _ = O.vq_encode(sd, torch.flip(x.cpu(), dims=[-1]))
     np.testing.assert_array_equal(codes[:, 1].reshape(-1).cpu().numpy(), idx_f.numpy())
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,ups,res,nchw,gn", [
+    (2, 8, 16, 128, 128, 3, 0, 1, 0, 1), (1, 16, 32, 256, 128, 3, 0, 0, 0, 1), (2, 16, 16, 128, 128, 3, 1, 0, 0, 0),
+    (1, 8, 32, 256, 128, 1, 0, 0, 0, 0), (2, 16, 16, 128, 3, 3, 0, 0, 1, 1), (1, 48, 48, 512, 256, 3, 0, 1, 0, 1),
+    (1, 24, 16, 64, 256, 3, 0, 0, 0, 0),
+])
+def test_conv_fused_vs_fp32_reference(B, H, W, Cin, Cout, k, ups, res, nchw, gn):
+    """lgen_conv_fused (GroupNorm-apply + swish + split on the tile load, halo tile in LDS, bias / residual / next-norm
+    statistics in the epilogue) against fp64 GroupNorm -> swish -> conv2d (vq_model.py:299-314, 354-378), plus the tile
+    partials -> lgen_gn_finalize -> (scale, shift) against the statistics of the stored output."""
+    from llamagen_amd.vq_engine import _ConvW
+    L, dev = _L(), _dev()
+    lib = L.lib()
+
+    class Cv:
+        pass
+    cv = Cv()
+    cv.weight = (_rand((Cout, Cin, k, k), 4) / (Cin * k * k) ** 0.5).to(dev)
+    cv.bias = (0.1 * _rand((Cout,), 5)).to(dev)
+    cw = _ConvW(cv)
+    Hs, Ws = (H // 2, W // 2) if ups else (H, W)
+    x = _rand((B, Hs, Ws, Cin), 6) * 1.5 + 0.3
+    r = _rand((B, H, W, Cout), 7) if res else None
+    xd = x.to(dev).contiguous()
+    coef = None
+    xin = x.permute(0, 3, 1, 2).double()
+    if gn:
+        gamma, beta = 1 + 0.1 * _rand((Cin,), 8), 0.1 * _rand((Cin,), 9)
+        nchunk = 3
+        ws = torch.empty(B * nchunk * 64, dtype=torch.float64, device=dev)
+        st = torch.empty(B, 32, 2, device=dev)
+        L.check(lib.lgen_gn_stats(L.ptr(xd), L.ptr(ws), L.ptr(st), B, Hs * Ws, Cin, 1e-6, nchunk, L.stream()), "stats")
+        coef = torch.empty(B, Cin, 2, device=dev)
+        g_d, b_d = gamma.to(dev), beta.to(dev)
+        L.check(lib.lgen_gn_finalize(0, L.ptr(st), L.ptr(g_d), L.ptr(b_d), L.ptr(coef), B, Cin, 0, 0, Hs * Ws, 1e-6, L.stream()), "fin")
+        xin = F.group_norm(xin, 32, gamma.double(), beta.double(), eps=1e-6)
+        xin = xin * torch.sigmoid(xin)
+    if ups:
+        xin = xin.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
+    ref = F.conv2d(xin, cv.weight.cpu().double(), cv.bias.cpu().double(), padding=k // 2).float()
+    if res:
+        ref = ref + r.permute(0, 3, 1, 2)
+    r_d = r.to(dev).contiguous() if res else None
+    out = torch.full((B * H * W * Cout,), float("nan"), device=dev)
+    ntiles = (H // 8) * (W // 16)
+    part = torch.full((B, ntiles, cw.fnpad // 4, 2), float("nan"), device=dev)
+    L.check(lib.lgen_conv_fused(L.ptr(xd), L.ptr(coef), 1 if gn else 0, L.ptr(cw.frag), L.ptr(cw.bias), L.ptr(r_d), L.ptr(out),
+                                L.ptr(part), B, H, W, Cin, Cout, cw.fnpad, k, ups, nchw, L.stream()), "conv_fused")
+    got = out.cpu().view(B, Cout, H, W) if nchw else out.cpu().view(B, H, W, Cout).permute(0, 3, 1, 2)
+    err = (got - ref).abs().max().item()
+    assert err < 6e-5 * max(1.0, ref.abs().max().item()), err
+    # statistics of what was stored, per (image, 4-channel quad), summed over tiles
+    nq = (Cout + 3) // 4
+    gq = torch.zeros(B, nq * 4, H * W)
+    gq[:, :Cout] = got.reshape(B, Cout, H * W)
+    gq = gq.view(B, nq, 4 * H * W).double()
+    ps = part.cpu().double().sum(1)[:, :nq]
+    np.testing.assert_allclose(ps[..., 0].numpy(), gq.sum(-1).numpy(), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(ps[..., 1].numpy(), (gq ** 2).sum(-1).numpy(), rtol=1e-5, atol=1e-3)
+    if Cout % 128 == 0:
+        g2, b2 = (1 + 0.1 * _rand((Cout,), 10)).to(dev), (0.1 * _rand((Cout,), 11)).to(dev)
+        c2 = torch.empty(B, Cout, 2, device=dev)
+        L.check(lib.lgen_gn_finalize(L.ptr(part), 0, L.ptr(g2), L.ptr(b2), L.ptr(c2), B, Cout, ntiles, cw.fnpad // 4, H * W, 1e-6,
+                                     L.stream()), "fin2")
+        gg = got.reshape(B, 32, -1).double()
+        mean, var = gg.mean(-1), gg.var(-1, unbiased=False)
+        rstd = 1 / torch.sqrt(var + 1e-6)
+        gs = Cout // 32
+        sc = rstd.repeat_interleave(gs, 1) * g2.cpu().double()
+        sh = b2.cpu().double() - sc * mean.repeat_interleave(gs, 1)
+        np.testing.assert_allclose(c2[..., 0].cpu().numpy(), sc.float().numpy(), rtol=2e-5)
+        np.testing.assert_allclose(c2[..., 1].cpu().numpy(), sh.float().numpy(), rtol=2e-5, atol=2e-5)
+
+
+def test_decode_code_fused_matches_unfused(monkeypatch):
+    """The fused decoder path (default) and the round-1 path (LGEN_VQ_FUSED=0: gn_stats + gn_swish_split + conv_igemm) agree to
+    fp32 rounding on a 128 px image (both paths in use: the 8x8 level is un-fusable, the 16 .. 128 px levels fused)."""
+    case = VQ_CASES["vq16_4x4"]
+    m, sd = build_vq_holder(case)
+    dev = _dev()
+    m = m.to(dev)
+    codes = torch.randint(0, 16384, (2, 64), generator=torch.Generator().manual_seed(5)).to(dev)
+    img = m.decode_code(codes, [2, 8, 8, 8])
+    assert m._engine.fused
+    monkeypatch.setenv("LGEN_VQ_FUSED", "0")
+    m._engine = None
+    img0 = m.decode_code(codes, [2, 8, 8, 8])
+    assert not m._engine.fused
+    assert (img - img0).abs().max().item() < 2e-4
+    ref = O.vq_decode_code(sd, codes.cpu(), [2, 8, 8, 8])
+    assert (img.cpu() - ref).abs().max().item() < 1e-3

@@ -1,0 +1,27 @@
+"""decode_code timing, fused (lgen_conv_fused) vs round-1 path (development aid)."""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from llamagen_amd import VQ_models
+
+def main(B=32, lat=24):
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    vq = VQ_models["VQ-16"](codebook_size=16384, codebook_embed_dim=8).to(dev).eval()
+    codes = torch.randint(0, 16384, (B, lat * lat), device=dev)
+    imgs = {}
+    for fused in ("1", "0"):
+        os.environ["LGEN_VQ_FUSED"] = fused
+        vq._engine = None
+        for r in range(4):
+            torch.cuda.synchronize(); t = time.time()
+            img = vq.decode_code(codes, [B, 8, lat, lat])
+            torch.cuda.synchronize(); dt = time.time() - t
+            fl = 3 * 570.1e9 * B * (lat / 24) ** 2
+            print(f"fused={fused} VQ-16 decode B={B} {lat*16}px: {dt*1e3:.1f} ms  {fl/dt/1e12:.1f} TFLOP/s (3-pass bf16)  mean={img.mean().item():.5f}", flush=True)
+        imgs[fused] = img
+    print("max |fused - unfused|:", (imgs["1"] - imgs["0"]).abs().max().item())
+
+if __name__ == "__main__":
+    a = sys.argv[1:]
+    main(int(a[0]) if a else 32, int(a[1]) if len(a) > 1 else 24)

@@ -122,7 +122,10 @@ __global__ __launch_bounds__(256, 2) void conv_fused_kernel(ConvFArgs a) {
                 }
                 if (a.swish) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) f[e] = f[e] / (1.0f + expf(-f[e]));
+                    // x * sigmoid(x) with the hardware exp / reciprocal (v_exp_f32, v_rcp_f32: ~1e-7 relative, far below
+                    // the 2^-16 of the hi/lo split that follows); IEEE expf + division cost ~30 VALU ops per element and
+                    // were a third of this kernel's issue cycles
+                    for (int e = 0; e < 8; ++e) f[e] = f[e] * __frcp_rn(1.0f + __expf(-f[e]));
                 }
                 uint4 hi, lo;
                 split8(f, hi, lo);
@@ -134,27 +137,30 @@ __global__ __launch_bounds__(256, 2) void conv_fused_kernel(ConvFArgs a) {
         }
     };
     const uint4* wbase = a.w + (size_t)nb * nkc * TAPS * (WT / 16);
-    uint4 wr0 = make_uint4(0, 0, 0, 0), wr1 = wr0, wr2 = wr0, wr3 = wr0;  // W_IT <= 4 staging registers (scalars: an
-    // indexed array here ends up in scratch memory -- hipcc does not promote it across the two loop levels)
-    auto gload_w = [&](int step_) {
+    // Two register staging sets for the (L2-resident) weight tiles: the loads of step s+2 are issued before the MFMAs
+    // of step s and written to LDS after the MFMAs of step s+1, so a load has two compute phases to land (with one set
+    // every step ended waiting out the L2 latency of the load it had just issued: 3900 cycles per step for 770 cycles
+    // of MFMA).  Scalars, not an indexed array: hipcc leaves such an array in scratch memory across the two loop levels.
+    uint4 wa0 = make_uint4(0, 0, 0, 0), wa1 = wa0, wa2 = wa0, wa3 = wa0, wb0 = wa0, wb1 = wa0, wb2 = wa0, wb3 = wa0;
+    auto gload_w = [&](int step_, uint4& r0, uint4& r1, uint4& r2, uint4& r3) {
         const int st_ = step_ < nsteps ? step_ : nsteps - 1;  // tail: harmless re-load
         const uint4* src = wbase + (size_t)st_ * (WT / 16);
         if constexpr (W_IT == 4) {
-            wr0 = src[t]; wr1 = src[t + 256]; wr2 = src[t + 512]; wr3 = src[t + 768];
+            r0 = src[t]; r1 = src[t + 256]; r2 = src[t + 512]; r3 = src[t + 768];
         } else if constexpr (W_IT == 2) {
-            wr0 = src[t]; wr1 = src[t + 256];
+            r0 = src[t]; r1 = src[t + 256];
         } else {
-            wr0 = src[t < WT / 16 ? t : 0];
+            r0 = src[t < WT / 16 ? t : 0];
         }
     };
-    auto lstore_w = [&](int buf_) {
+    auto lstore_w = [&](int buf_, const uint4& r0, const uint4& r1, const uint4& r2, const uint4& r3) {
         unsigned char* dst = sW + buf_ * WT + t * 16;
         if constexpr (W_IT == 4) {
-            *(uint4*)(dst) = wr0; *(uint4*)(dst + 4096) = wr1; *(uint4*)(dst + 8192) = wr2; *(uint4*)(dst + 12288) = wr3;
+            *(uint4*)(dst) = r0; *(uint4*)(dst + 4096) = r1; *(uint4*)(dst + 8192) = r2; *(uint4*)(dst + 12288) = r3;
         } else if constexpr (W_IT == 2) {
-            *(uint4*)(dst) = wr0; *(uint4*)(dst + 4096) = wr1;
+            *(uint4*)(dst) = r0; *(uint4*)(dst + 4096) = r1;
         } else {
-            if (t < WT / 16) *(uint4*)(dst) = wr0;
+            if (t < WT / 16) *(uint4*)(dst) = r0;
         }
     };
     static_assert(W_IT == 4 || W_IT == 2 || (W_IT == 1 && WT / 16 <= 256), "weight tile staging shape");
@@ -189,23 +195,31 @@ __global__ __launch_bounds__(256, 2) void conv_fused_kernel(ConvFArgs a) {
         }
     };
 
-    gload_w(0);
+    gload_w(0, wa0, wa1, wa2, wa3);
     CF_GLOAD_HALO(0);
-    lstore_w(0);
-    for (int kc = 0; kc < nkc; ++kc) {
-        // every wave has finished reading the previous chunk's halo (barrier at the end of its last tap)
-        store_halo();
-        __syncthreads();
-        if (kc + 1 < nkc) CF_GLOAD_HALO(kc + 1);  // lands during the taps of this chunk
-
-        for (int tap = 0; tap < TAPS; ++tap) {
-            const int s = kc * TAPS + tap;
-            gload_w(s + 1);
-            compute(s & 1, tap);
-            lstore_w((s + 1) & 1);
-            __syncthreads();
-        }
+    gload_w(1, wb0, wb1, wb2, wb3);
+    lstore_w(0, wa0, wa1, wa2, wa3);
+    int kc = 0, tap = 0;
+    // one step = one filter tap of one 32-channel chunk; LD* = the set whose contents (step s) are already in LDS,
+    // ST* = the set holding step s+1
+#define CF_STEP(s_, cur_, LD0, LD1, LD2, LD3, ST0, ST1, ST2, ST3)                                   \
+    {                                                                                               \
+        if (tap == 0) { /* every wave is past the barrier that ended the previous chunk's last tap */ \
+            store_halo();                                                                           \
+            __syncthreads();                                                                        \
+            if (kc + 1 < nkc) CF_GLOAD_HALO(kc + 1); /* lands during the taps of this chunk */     \
+        }                                                                                           \
+        gload_w((s_) + 2, LD0, LD1, LD2, LD3);                                                      \
+        compute(cur_, tap);                                                                         \
+        lstore_w((cur_) ^ 1, ST0, ST1, ST2, ST3);                                                   \
+        __syncthreads();                                                                            \
+        if (++tap == TAPS) { tap = 0; ++kc; }                                                       \
     }
+    for (int s = 0; s < nsteps; s += 2) {
+        CF_STEP(s, 0, wa0, wa1, wa2, wa3, wb0, wb1, wb2, wb3);
+        if (s + 1 < nsteps) CF_STEP(s + 1, 1, wb0, wb1, wb2, wb3, wa0, wa1, wa2, wa3);
+    }
+#undef CF_STEP
 #undef CF_GLOAD_HALO
 
     // epilogue: lane holds channels n = n0 + g*4 + {0..3} of pixel (y0 + row, x0 + fr)
@@ -219,8 +233,13 @@ __global__ __launch_bounds__(256, 2) void conv_fused_kernel(ConvFArgs a) {
         const int n = nb * BN + nl;
         float bs[4] = {0.f, 0.f, 0.f, 0.f};
         if (a.bias) {
+            if (n + 3 < a.Cout) {
+                const float4 bv = *(const float4*)(a.bias + n);
+                bs[0] = bv.x; bs[1] = bv.y; bs[2] = bv.z; bs[3] = bv.w;
+            } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) bs[e] = n + e < a.Cout ? a.bias[n + e] : 0.f;
+                for (int e = 0; e < 4; ++e) bs[e] = n + e < a.Cout ? a.bias[n + e] : 0.f;
+            }
         }
         float ssum = 0.f, sq = 0.f;
 #pragma unroll

@@ -35,9 +35,11 @@ LAT = IMG // 16
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured copy)
 
 
-def build_models(dev, seed):
+def build_models(dev, weight_seed=0):
+    """Every rank builds the SAME model (the reference's DDP replicas load one checkpoint); only labels and
+    sampling noise are per-rank (sample_c2i_ddp.py:47), seeded by the caller afterwards."""
     from llamagen_amd import GPT_models, VQ_models
-    torch.manual_seed(seed)
+    torch.manual_seed(weight_seed)
     gpt = GPT_models[GPT_NAME](vocab_size=16384, block_size=LAT * LAT, num_classes=1000, cls_token_num=1,
                                model_type="c2i")
     torch.nn.init.normal_(gpt.output.weight, 0, 0.02)  # zero-initialised in the reference (gpt.py:305)
@@ -98,64 +100,149 @@ def measure_attention(gpt, B2, N, npos=12, reps=5):
     return total_us * e.L * 1e-6, N * e.L, dict(zip(pts, [round(u, 2) for u in us]))
 
 
-def cpu_baseline(steps=12):
-    """The CPU oracle (oracle/llamagen_oracle.py, a port of the reference path) on a bounded sample of
-    the same workload: GPT-L 384 px, ONE image (CFG batch 2), `steps` decode steps at the START of the
-    sequence and `steps` at the END (kv_len ~ 576, the expensive end), plus a full VQ decode of one
-    384 px image; extrapolated linearly to images/s over 576 tokens.  The thread count is calibrated
-    first (torch's intra-op pool thrashes on these small GEMVs with one thread per logical core of a
-    big host): the best of {8, 16, 32, 64} <= cpu_count is used and reported as `cores`."""
+def measure_gemms(gpt, reps=5):
+    """Second kernel family of the decode step (HBM / latency-bound skinny GEMMs): live HIP-event timing of captured
+    chains that contain ONLY one kind of GEMM, over all layers' weights in turn (nothing cache-resident), with the
+    tile shapes the decode graph uses.  Returns {kind: (us per launch, weight bytes per launch)}."""
+    from llamagen_amd import _lib as L
+    e = gpt._engine
+    lib, dt, M, mts = e.lib, e.dt, e.B2, e.MTs
+    d, F, H, hd, hdp, S8, V = e.d, e.F, e.H, e.hd, e.hdp, e.S8, e.V
+    tq, to, t13, t2, th = (e._tiles("qkv", 3 * d, d), e._tiles("wo", d, d), e._tiles("w13", 2 * F, d), e._tiles("w2", d, F),
+                           e._tiles("head", V, d))
+    e.ssq_parts = d // 16
+    e.state.zero_()
+    nw = lambda w: w if e.fuse_norm else None
+
+    def qkv():
+        for w in e.layers:
+            L.check(lib.lgen_gemm_qkv_rope(L.ptr(w["wqkv"]), L.ptr(e.hp), L.ptr(e.qbuf), L.ptr(e.k_cache[0]), L.ptr(e.v_cache[0]),
+                                           L.ptr(e.freqs_cis), L.ptr(e.state), M, mts, d, H, hd, hdp, S8, e.kvs, dt, tq[0], tq[1], tq[2],
+                                           L.ptr(nw(w["an"])), L.ptr(e.ssq if e.fuse_norm else None), e.ssq_parts, e.eps, L.stream()), "qkv")
+    kinds = {
+        "wqkv": (qkv, 3 * d * d),
+        "wo": (lambda: [e.gemm(w["wo"], e.ap, e.hp, M, mts, d, d, L.EPI_RES, to, ssq_out=e.ssq if e.fuse_norm else None) for w in e.layers], d * d),
+        "w13": (lambda: [e.gemm(w["w13"], e.hp, e.gp, M, mts, 2 * F, d, L.EPI_SWIGLU, t13, norm_w=nw(w["fn"])) for w in e.layers], 2 * F * d),
+        "w2": (lambda: [e.gemm(w["w2"], e.gp, e.hp, M, mts, d, F, L.EPI_RES, t2, ssq_out=e.ssq if e.fuse_norm else None) for w in e.layers], F * d),
+        "lm_head": (lambda: [e.gemm(e.out_w, e.hp, e.logits, M, mts, V, d, L.EPI_ROWS, th, norm_w=nw(e.norm_w)) for _ in range(4)], V * d),
+    }
+    esz = 2 if e.dtype == torch.bfloat16 else 4
+    stream = torch.cuda.Stream()
+    out = {}
+    with torch.cuda.stream(stream):
+        for kind, (fn, nparam) in kinds.items():
+            launches = 4 if kind == "lm_head" else e.L
+            fn()
+            stream.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=stream):
+                fn()
+            best = 1e30
+            for _ in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                for _ in range(reps):
+                    g.replay()
+                e1.record(stream)
+                stream.synchronize()
+                best = min(best, e0.elapsed_time(e1) * 1e3 / (reps * launches))
+            out[kind] = (best, nparam * esz)
+    return out
+
+
+def _cpu_decode_fns():
+    """(kind, setup, step) for the CPU leg: the reference's own modules when /root/reference is importable (build
+    container), else the oracle port (the GPU box has no reference mount).  Both run GPT-L bf16 at B = 32 (CFG rows 64)."""
+    N = LAT * LAT
+    try:
+        if not os.path.isdir("/root/reference") or os.environ.get("LGEN_BENCH_CPU_PORT") == "1":
+            raise ImportError("no reference mount")
+        sys.path.insert(0, "/root/reference")
+        from autoregressive.models.gpt import GPT_models as RG
+        from autoregressive.models.generate import decode_one_token
+        from tokenizer.tokenizer_image.vq_model import VQ_models as RV
+        torch.manual_seed(0)
+        m = RG[GPT_NAME](vocab_size=16384, block_size=N, num_classes=1000, cls_token_num=1, model_type="c2i")
+        torch.nn.init.normal_(m.output.weight, 0, 0.02)
+        m = m.to(torch.bfloat16).eval()
+        with torch.device("cpu"):
+            m.setup_caches(max_batch_size=2 * BATCH, max_seq_length=1 + N, dtype=torch.bfloat16)
+        for blk in m.layers:
+            blk.attention.kv_cache.k_cache.normal_(0, 1)
+            blk.attention.kv_cache.v_cache.normal_(0, 1)
+        tok = torch.randint(0, 16384, (BATCH, 1))
+
+        def step(pos):
+            with torch.no_grad():
+                decode_one_token(m, tok, torch.tensor([pos]), CFG, True, temperature=1.0, top_k=TOPK, top_p=1.0, sample_logits=True)
+        vq = RV["VQ-16"](codebook_size=16384, codebook_embed_dim=8).eval()
+
+        def vq_decode(codes, shape):
+            with torch.no_grad():
+                return vq.decode_code(codes, shape)
+        return "reference", step, vq_decode
+    except Exception:  # noqa: BLE001 -- any import / construction problem: use the port
+        pass
     from llamagen_amd import GPT_models, VQ_models
     from oracle import llamagen_oracle as O
-    ncpu = os.cpu_count() or 1
     torch.manual_seed(0)
-    m = GPT_models[GPT_NAME](vocab_size=16384, block_size=LAT * LAT, num_classes=1000, cls_token_num=1, model_type="c2i")
+    m = GPT_models[GPT_NAME](vocab_size=16384, block_size=N, num_classes=1000, cls_token_num=1, model_type="c2i")
     torch.nn.init.normal_(m.output.weight, 0, 0.02)
-    sd = {k: v for k, v in m.state_dict().items()}
-    cfg = O.GPTConfig(**O.GPT_SIZES[GPT_NAME], vocab_size=16384, block_size=LAT * LAT, num_classes=1000, cls_token_num=1)
-    model = O.GPTOracle(cfg, sd, torch.bfloat16)
-    N = LAT * LAT
-    model.setup_caches(2, 1 + N)
+    cfg = O.GPTConfig(**O.GPT_SIZES[GPT_NAME], vocab_size=16384, block_size=N, num_classes=1000, cls_token_num=1)
+    model = O.GPTOracle(cfg, dict(m.state_dict()), torch.bfloat16)
+    model.setup_caches(2 * BATCH, 1 + N)
     for kc, vc in zip(model.k_cache, model.v_cache):  # plausible cache contents for the late steps
         kc.normal_(0, 1)
         vc.normal_(0, 1)
-    tok = torch.randint(0, 16384, (2, 1))
+    tok = torch.randint(0, 16384, (BATCH, 1))
 
-    def decode(pos):
-        lg = model.forward(tok, None, torch.tensor([pos]))
+    def step(pos):
+        lg = model.forward(torch.cat([tok, tok]), None, torch.tensor([pos]))
         O.sample(O.cfg_mix(lg, CFG)[:, -1], top_k=TOPK)
+    vsd = dict(VQ_models["VQ-16"](codebook_size=16384, codebook_embed_dim=8).state_dict())
+    return "port", step, (lambda codes, shape: O.vq_decode_code(vsd, codes, shape))
 
+
+def cpu_baseline(steps=16, budget_s=30.0):
+    """CPU leg beside the GPU number (SURVEY 8d / BASELINE.md 4): the same workload -- GPT-L 384 px, B = 32, cfg 4.0 (64
+    rows), top-k 2000, bf16 -- on the host cores, as a BOUNDED 32-step slice: `steps` decode steps at the start of the
+    sequence and `steps` at its end (kv_len ~ 576), plus the VQ decode of 2 images; images/s = 32 / (mean step time x
+    576 + 32 x VQ time per image).  Linear extrapolation, labelled as such.  The thread count is calibrated first
+    (torch's intra-op pool thrashes on a big host with one thread per logical core) and reported next to the core count."""
+    ncpu = os.cpu_count() or 1
+    kind, step, vq_decode = _cpu_decode_fns()
+    N = LAT * LAT
     best_thr, best_t = 1, 1e30
-    for thr in [t for t in (8, 16, 32, 64) if t <= ncpu] or [ncpu]:
+    for thr in [t for t in (8, 16, 32, 64, 128) if t <= ncpu] or [ncpu]:
         torch.set_num_threads(thr)
-        decode(N // 2)  # warm-up at this thread count
+        step(N // 2)  # warm-up at this thread count
         t0 = time.time()
-        decode(N // 2)
-        decode(N // 2 + 1)
-        t = (time.time() - t0) / 2
+        step(N // 2)
+        t = time.time() - t0
         if t < best_t:
             best_thr, best_t = thr, t
     torch.set_num_threads(best_thr)
+    steps = max(2, min(steps, int(budget_s / 2 / max(best_t, 1e-3))))  # keep the whole leg near `budget_s`
     t0 = time.time()
-    for i in range(steps):  # early steps
-        decode(1 + i)
+    for i in range(steps):
+        step(1 + i)
     t_early = (time.time() - t0) / steps
     t0 = time.time()
-    for i in range(steps):  # late steps
-        decode(N - steps + i)
+    for i in range(steps):
+        step(N - steps + i)
     t_late = (time.time() - t0) / steps
-    vq = VQ_models["VQ-16"](codebook_size=16384, codebook_embed_dim=8)
-    vsd = {k: v for k, v in vq.state_dict().items()}
-    codes = torch.randint(0, 16384, (1, N))
-    O.vq_decode_code(vsd, codes[:, :16], [1, 8, 4, 4])  # warm-up
+    codes = torch.randint(0, 16384, (2, N))
+    vq_decode(codes[:1, :16], [1, 8, 4, 4])  # warm-up
     t0 = time.time()
-    O.vq_decode_code(vsd, codes, [1, 8, LAT, LAT])
-    t_vq = time.time() - t0
-    per_image = 0.5 * (t_early + t_late) * N + t_vq
-    return {"value": round(1.0 / per_image, 5), "unit": "images/s", "cores": best_thr, "kind": "port",
-            "sample": f"oracle on GPT-L 384px, 1 image (CFG batch 2), {best_thr} threads of {ncpu} logical cores: {steps} early + "
-                      f"{steps} late decode steps ({t_early*1e3:.0f}/{t_late*1e3:.0f} ms/step) extrapolated linearly to 576 "
-                      f"tokens + one full VQ decode ({t_vq:.1f} s)"}
+    vq_decode(codes, [2, 8, LAT, LAT])
+    t_vq = (time.time() - t0) / 2
+    per_batch = 0.5 * (t_early + t_late) * N + BATCH * t_vq
+    return {"value": round(BATCH / per_batch, 5), "unit": "images/s (B=32 slice, extrapolated)", "cores": best_thr,
+            "logical_cores": ncpu, "kind": kind,
+            "sample": f"{'reference modules' if kind == 'reference' else 'oracle port (no /root/reference on this box)'}, GPT-L 384px "
+                      f"bf16 at B=32 (64 CFG rows), {best_thr} threads of {ncpu} logical cores: {steps} early + {steps} late "
+                      f"decode steps ({t_early*1e3:.0f} / {t_late*1e3:.0f} ms per step) extrapolated linearly to 576 tokens, "
+                      f"+ 32 x the VQ decode time of one 384 px image ({t_vq:.2f} s, measured on 2)"}
 
 
 def main():
@@ -182,8 +269,8 @@ def main():
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
     torch.set_grad_enabled(False)
-    seed = ldist.rank_seed(0, rank, world)
-    gpt, vq = build_models(dev, seed)
+    gpt, vq = build_models(dev, 0)
+    torch.manual_seed(ldist.rank_seed(0, rank, world))  # per-rank labels / sampling noise only
     skw = dict(cfg_scale=CFG, cfg_interval=-1, temperature=1.0, top_k=TOPK, top_p=1.0, sample_logits=True)
     N = LAT * LAT
     if args.lanes <= 0:
@@ -196,11 +283,18 @@ def main():
     pipe.prepare(BATCH, N, **skw)  # setup (like loading weights): KV slabs, workspaces, decode graphs per lane
     torch.cuda.synchronize()
 
+    from llamagen_amd.postprocess import to_uint8_hwc
+
+    def finish(job_id, idx, img):
+        """Per batch, enqueued on its lane's stream as soon as decode_code() is: fp32 [-1, 1] -> uint8 HWC (what the
+        reference writes out, sample_c2i_ddp.py:143) and the step's ONE collective (uint8 gather to rank 0)."""
+        return ldist.gather_to_root(to_uint8_hwc(img))
+
     def run_steps(k):
-        """k steps; step = one batch of BATCH images through generate() + decode_code(); consecutive steps
-        ride on alternating lanes.  ONE collective (gather to rank 0) per step, issued once the images exist."""
+        """k steps; step = one batch of BATCH images through generate() + decode_code() + uint8 conversion
+        [+ gather]; consecutive steps ride on alternating lanes."""
         conds = [torch.randint(0, 1000, (BATCH,), device=dev) for _ in range(k)]
-        return [ldist.gather_to_root(img) for _, img in pipe.run(conds, N, **skw)]
+        return pipe.run(conds, N, on_done=finish, **skw)
 
     def fence():
         if world > 1:
@@ -231,8 +325,11 @@ def main():
 
     if rank == 0:
         out = outs[-1]
-        assert out is not None and out.shape[0] == BATCH * world and torch.isfinite(out).all()
+        assert out is not None and out.shape[0] == BATCH * world and out.dtype == torch.uint8 and tuple(out.shape[1:]) == (IMG, IMG, 3)
+        assert 8 < float(out.float().std()) < 128  # images, not a constant
         value = BATCH * world * args.steps / dt
+        if lane1 is None:
+            lane1 = value
         res = {"metric": "images/sec (whole node), LlamaGen-L 384px c2i", "value": round(value, 3), "unit": "images/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
@@ -240,22 +337,41 @@ def main():
                                       "bf16) + VQ-16 decode_code (fp32-class), batch 32 per step per GPU, random-init "
                                       f"weights; {args.lanes} steps in flight per GPU on separate HIP streams",
                           "global_batch": BATCH * world, "tokens_per_image": N, "parallelism": f"dp{world}",
-                          "steps_in_flight_per_gpu": args.lanes,
-                          "images_per_s_with_one_step_in_flight": None if lane1 is None else round(lane1, 3)}}
+                          "steps_in_flight_per_gpu": args.lanes},
+               # the same workload with ONE generate() + decode_code() in flight at a time (no cross-batch overlap)
+               "images_per_s_with_one_step_in_flight": None if lane1 is None else round(lane1, 3)}
+        pmc = {}
+        try:  # PMC passes of THIS round (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs; tools/pmc_summary.py)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc.json")))
+        except Exception:  # noqa: BLE001
+            pass
         if not args.no_roofline:
             sec, launches, per_pos = measure_attention(pipe.lanes[0].gpt, 2 * BATCH, N)
             nbytes, nl = attention_bytes_per_generate(gpt.config, 2 * BATCH, N)
             assert nl == launches, (nl, launches)
             ach = nbytes / sec / 1e9
+            pa = pmc.get("attn_decode_kernel")
             res["roofline"] = {"bound": "hbm", "kernel": "attn_decode_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                               # PMC pass (profiles/r01_attn_decode_pmc.csv: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-                               # separate runs, FETCH x2 gfx950 correction): fetched = 1.002 x algorithmic KV bytes,
-                               # written = the 128 KiB output tile -> per average launch:
-                               "traffic": int(1.002 * nbytes / launches + 131072),
+                               # HBM bytes per average launch from the committed PMC pass (not a live counter): measured
+                               # fetch/algorithmic ratio x this run's algorithmic bytes + measured bytes written
+                               "traffic": None if pa is None else int(pa["fetch_over_algorithmic"] * nbytes / launches + pa["write_bytes_per_launch"]),
+                               "traffic_source": None if pa is None else pa.get("source"),
                                "avg_launch_us": round(sec / launches * 1e6, 2),
                                "algorithmic_bytes_per_launch": int(nbytes / launches),
                                "launch_us_by_position": per_pos}
+            gm = measure_gemms(pipe.lanes[0].gpt)
+            nlay = gpt.config.n_layer
+            tot_us = sum(us * (1 if k == "lm_head" else nlay) for k, (us, _) in gm.items())
+            tot_b = sum(b * (1 if k == "lm_head" else nlay) for k, (_, b) in gm.items())
+            res["roofline_gemm"] = {"bound": "hbm", "kernel": "gemm_normpre_kernel / gemm_kernel (skinny weight-streaming GEMMs, M = 64)",
+                                    "achieved": round(tot_b / tot_us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": round(tot_b / tot_us / 1e3 / HBM_PEAK_GBS, 4),
+                                    "weight_bytes_per_step": int(tot_b), "us_per_step": round(tot_us, 1),
+                                    "per_launch": {k: {"us": round(us, 2), "weight_bytes": int(b), "GB/s": round(b / us / 1e3, 1),
+                                                       "fetch_over_algorithmic": (pmc.get("gemm", {}).get(k) or {}).get("fetch_over_algorithmic")}
+                                                   for k, (us, b) in gm.items()},
+                                    "traffic_source": (pmc.get("gemm") or {}).get("source")}
         if not args.no_roofline:
             # second hot kernel family (MFMA-bound): the VQ decoder's implicit-GEMM convolutions.  570.1 GFLOP per
             # 384 px image x 3 split-bf16 MFMA passes, timed live over whole decode_code()

@@ -84,6 +84,10 @@ class PackedWeights:
             self.fc1 = pack_weight(cast(model.cls_embedding.cap_proj.fc1.weight))
             self.fc2 = pack_weight(cast(model.cls_embedding.cap_proj.fc2.weight))
             self.cap_hidden = model.cls_embedding.cap_proj.fc1.weight.shape[0]
+        # The packed copies are built by asynchronous kernels on the constructing stream and then shared by every lane
+        # (other streams, no event dependency): finish them here, once, so that no lane can read a half-built copy.
+        if self.tok_emb.is_cuda:
+            torch.cuda.current_stream(self.tok_emb.device).synchronize()
 
 
 _PACKED = weakref.WeakKeyDictionary()  # tok_embeddings module (shared by lane views) -> PackedWeights

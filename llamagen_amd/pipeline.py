@@ -142,8 +142,12 @@ class SamplingPipeline:
         self.run(conds, max_new_tokens, **gen_kw)
         torch.cuda.synchronize(self.dev)
 
-    def run(self, conds: Sequence[torch.Tensor], max_new_tokens: int, decode_shape=None,
+    def run(self, conds: Sequence[torch.Tensor], max_new_tokens: int, decode_shape=None, on_done=None,
             **gen_kw) -> List[Tuple[torch.Tensor, Optional[torch.Tensor]]]:
+        """on_done(job_id, ids, images) (optional) is called as soon as a batch's decode_code() has been ENQUEUED, with
+        that lane's stream current -- the place to enqueue per-batch post-processing and the step's collective
+        (dist.gather_to_root) so that it overlaps the other lanes' decode steps; its return value replaces
+        (ids, images) in the result list."""
         results = [None] * len(conds)
         nxt = 0
         while True:
@@ -157,7 +161,11 @@ class SamplingPipeline:
             for lane in active:
                 done = lane.advance(self.steps_per_turn)
                 if done is not None:
-                    results[done[0]] = (done[1], done[2])
+                    if on_done is not None:
+                        with torch.cuda.stream(lane.vq_stream), torch.no_grad():
+                            results[done[0]] = on_done(*done)
+                    else:
+                        results[done[0]] = (done[1], done[2])
         cur = torch.cuda.current_stream(self.dev)
         for lane in self.lanes:
             cur.wait_stream(lane.stream)

@@ -101,6 +101,9 @@ class VQEngine:
         self._cb = cb
         self._enc = None
         self._model_ref = model
+        # weight planes / codebook prep were enqueued on the constructing stream; lanes use this engine from their own
+        # streams without an event dependency, so finish the one-time setup here
+        torch.cuda.current_stream(self.dev).synchronize()
 
     @staticmethod
     def _sig(model):

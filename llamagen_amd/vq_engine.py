@@ -310,23 +310,31 @@ class VQEngine:
         cin = E["conv_in"].cin
         xp = torch.zeros(B, H, W, cin, dtype=torch.float32, device=self.dev)  # NHWC, RGB padded to one 32-channel K-step
         xp[..., :Cx] = x.to(self.dev, torch.float32).permute(0, 2, 3, 1)
-        h = self._conv(self._split(xp.reshape(-1), B, H * W, cin), E["conv_in"], B, H, W)
+        fz = lambda hh, ww: self.fused and self._fusable(hh, ww)
+        if fz(H, W):
+            h = self._convf(_Act(xp.reshape(-1)), E["conv_in"], B, H, W)
+        else:
+            h = _Act(self._conv(self._split(xp.reshape(-1), B, H * W, cin), E["conv_in"], B, H, W))
         for lv in E["levels"]:
             for bi, rp in enumerate(lv["res"]):
                 h = self._res(h, rp, B, H, W)
                 if lv["attn"]:
                     h = self._attn(h, lv["attn"][bi], B, H, W)
-            if lv["down"] is not None:
+            if lv["down"] is not None:  # stride-2 Downsample conv (vq_model.py:389-393): implicit-GEMM path
                 c = lv["down"].cin
-                h = self._conv(self._split(h, B, H * W, c), lv["down"], B, H // 2, W // 2, upsample=2)
+                h = _Act(self._conv(self._split(h.t, B, H * W, c), lv["down"], B, H // 2, W // 2, upsample=2))
                 H, W = H // 2, W // 2
         h = self._res(h, E["mid"][0], B, H, W)
         h = self._attn(h, E["mid"][1], B, H, W)
         h = self._res(h, E["mid"][2], B, H, W)
         c = E["conv_out"].cin
-        h = self._conv(self._split(h, B, H * W, c, E["norm_out"], True), E["conv_out"], B, H, W)
         zc = E["quant"].cin
-        z = self._conv(self._split(h, B, H * W, zc), E["quant"], B, H, W, out_nchw=True).view(B, self.e_dim, H, W)
+        if fz(H, W):
+            h = self._convf(h, E["conv_out"], B, H, W, coef=self._coef(h, E["norm_out"], B, H * W, c), swish=True, want_part=False)
+            z = self._convf(h, E["quant"], B, H, W, out_nchw=True, want_part=False).t.view(B, self.e_dim, H, W)
+        else:
+            h = self._conv(self._split(h.t, B, H * W, c, E["norm_out"], True), E["conv_out"], B, H, W)
+            z = self._conv(self._split(h, B, H * W, zc), E["quant"], B, H, W, out_nchw=True).view(B, self.e_dim, H, W)
         idx = self.argmin(z)
         emb = self.cbn if self.l2 else self._cb
         quant = emb[idx].view(B, H, W, self.e_dim).permute(0, 3, 1, 2).contiguous()  # gather of codebook rows (no arithmetic)

@@ -208,8 +208,15 @@ class VQModel(nn.Module):
         -> (quant [B, e_dim, h, w], (None, None, None, 0), (None, None, indices int64 [B*h*w]))."""
         return self._eng().encode(x)
 
+    @torch.no_grad()
     def forward(self, input):
-        raise NotImplementedError("training forward (vq_model.py:57-60) is outside the sampling hot path")
+        """vq_model.py:57-60 in eval mode (the form reconstruction_vq_ddp.py / vq_demo.py call): encode -> decode,
+        returns (reconstruction [B, 3, H, W], emb_loss tuple).  Train mode (losses, straight-through gradient) is
+        outside the sampling hot path."""
+        if self.training:
+            raise NotImplementedError("train-mode VQModel.forward (losses + backward) is outside the sampling hot path")
+        quant, diff, _ = self.encode(input)
+        return self.decode(quant), diff
 
 
 def VQ_8(**kwargs):

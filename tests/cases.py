@@ -69,6 +69,8 @@ VQ_CASES = {
     "enc16_32x32": dict(kind="encode", vq="VQ-16", codebook_size=16384, embed_dim=8, wseed=6, rseed=26, batch=2, h=32, w=32),
     "enc16_48x32": dict(kind="encode", vq="VQ-16", codebook_size=16384, embed_dim=8, wseed=6, rseed=27, batch=1, h=48, w=32),
     "enc8_16x16": dict(kind="encode", vq="VQ-8", codebook_size=16384, embed_dim=8, wseed=7, rseed=28, batch=2, h=16, w=16),
+    # 256 px batch -> 2 x 16 x 16 = 512 latent vectors: the index-parity gate of VQModel.encode (extract_codes_c2i.py:92-111)
+    "enc16_256": dict(kind="encode", vq="VQ-16", codebook_size=16384, embed_dim=8, wseed=8, rseed=29, batch=2, h=256, w=256),
 }
 
 

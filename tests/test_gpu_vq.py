@@ -154,9 +154,12 @@ def test_decode_quant_path_and_larger_grid():
 
 @pytest.mark.parametrize("name", [k for k, c in VQ_CASES.items() if c["kind"] == "encode"])
 def test_encode_matches_reference_golden(name):
-    """VQModel.encode on the HIP path: latent (quant_conv output) within 1e-3 abs of the reference, indices
-    exactly the argmin of OUR latent (oracle argmin), and equal to the reference's wherever the latent error
-    cannot flip the nearest entry."""
+    """VQModel.encode on the HIP path (vq_model.py:41-45, 215-232; caller extract_codes_c2i.py:92-111).
+    Float part: latent (quant_conv output) within 1e-3 abs of the reference.  Integer part, by a MARGIN RULE: the
+    argmin over 16384 entries can only legitimately differ from the reference's where the reference's own top-2
+    distance margin is smaller than what the latent difference can move a distance by (|d - d'| <= 2 |n - n'| for unit
+    codebook rows, n = normalised latent); wherever the margin exceeds twice that bound the index MUST be identical,
+    and the indices are always exactly the argmin of OUR latent (oracle argmin)."""
     case = VQ_CASES[name]
     gold = load_golden("vq_" + name)
     m, sd = build_vq_holder(case)
@@ -165,14 +168,28 @@ def test_encode_matches_reference_golden(name):
     quant, losses, (_, _, idx) = m.encode(x.to(_dev()))
     z = m._engine.last_latent.cpu()
     assert tuple(z.shape) == gold["latent"].shape and idx.dtype == torch.int64 and losses == (None, None, None, 0)
-    err = np.abs(z.numpy() - gold["latent"]).max()
+    zr = torch.from_numpy(gold["latent"])
+    err = (z - zr).abs().max().item()
     assert err < 1e-3, err
-    np.testing.assert_array_equal(idx.cpu().numpy(), O.codebook_argmin(sd["quantize.embedding.weight"], z).numpy())
-    match = (idx.cpu().numpy() == gold["indices"]).mean()
-    assert match >= 0.75, match
-    zq_ref = O.get_codebook_entry(sd["quantize.embedding.weight"], idx.cpu(), list(z.shape))
+    cb = sd["quantize.embedding.weight"]
+    np.testing.assert_array_equal(idx.cpu().numpy(), O.codebook_argmin(cb, z).numpy())
+    # margin rule against the reference's indices
+    e = O.l2_normalize(cb).double()
+    flat = lambda t: t.permute(0, 2, 3, 1).reshape(-1, t.shape[1]).double()
+    nr, no = torch.nn.functional.normalize(flat(zr), dim=-1), torch.nn.functional.normalize(flat(z), dim=-1)
+    d = (nr ** 2).sum(-1, keepdim=True) + (e ** 2).sum(-1)[None] - 2 * nr @ e.t()
+    top2 = torch.topk(d, 2, dim=-1, largest=False).values
+    margin = top2[:, 1] - top2[:, 0]
+    bound = 2 * (no - nr).norm(dim=-1)
+    same = torch.from_numpy(gold["indices"]) == idx.cpu()
+    decided = margin > 2 * bound
+    assert bool(same[decided].all()), ("index differs where the reference margin decides it", int((~same[decided]).sum()))
+    match = same.float().mean().item()
+    # measured on MI355X: every golden vector (512 of them in enc16_256) is decided by its margin and reproduced exactly
+    assert decided.float().mean().item() >= 0.98 and match == 1.0, (decided.float().mean().item(), match)
+    zq_ref = O.get_codebook_entry(cb, idx.cpu(), list(z.shape))
     assert (quant.cpu() - zq_ref).abs().max().item() < 1e-6
-    print(name, "latent max abs err", err, "index match vs reference", match)
+    print(name, "latent max abs err", err, "index match vs reference", match, "of", same.numel(), "decided by margin", decided.float().mean().item())
 
 
 def test_conv_stride2_downsample_vs_fp32_conv():
@@ -213,6 +230,8 @@ def test_encode_decode_round_trip_256px():
     assert (m.decode(quant) - img).abs().max().item() < 1e-5
     _, _, (_, _, idx2) = m.encode(x)
     assert torch.equal(idx, idx2)
+    rec, diff = m(x)  # VQModel.forward (vq_model.py:57-60, eval): encode -> decode
+    assert torch.equal(rec, m.decode(quant)) and diff == (None, None, None, 0)
 
 
 @pytest.mark.parametrize("B,Hi,Ho", [(2, 384, 256), (1, 24, 16), (3, 20, 32), (1, 7, 7)])

@@ -17,11 +17,14 @@ def _worker(rank, world, port, q):
     n = 4
     local = torch.full((n, 2, 3), float(rank)) + torch.arange(n).view(n, 1, 1) * 10  # value = 10*i + rank
     out = gather_to_root(local)
+    u8 = gather_to_root((local[:, :1] % 251).to(torch.uint8))  # the bench gathers uint8 HWC images
     dist.barrier()
     if rank == 0:
+        assert u8.dtype == torch.uint8 and u8.shape == (n * world, 1, 3) and out.is_contiguous()
+        assert all(int(u8[g, 0, 0]) == (10 * (g // world) + g % world) % 251 for g in range(n * world))
         q.put(out.clone())
     else:
-        assert out is None
+        assert out is None and u8 is None
     dist.destroy_process_group()
 
 

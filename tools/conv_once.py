@@ -1,0 +1,29 @@
+"""A few launches of ONE fused-conv shape (profiling target): python tools/conv_once.py [B] [H] [Cin] [Cout] [reps] [variant]"""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from llamagen_amd import _lib as L
+from llamagen_amd.vq_engine import _ConvW
+a = sys.argv[1:]
+B, H, Cin, Cout, reps = (int(a[i]) if len(a) > i else d for i, d in enumerate((16, 384, 128, 128, 5)))
+variant = int(a[5]) if len(a) > 5 else 0
+abl = int(a[6]) if len(a) > 6 else 0  # 1: no GroupNorm/swish, 2: no residual, 4: no statistics partials
+dev = torch.device("cuda:0")
+lib = L.lib()
+torch.manual_seed(0)
+class Cv: pass
+cv = Cv(); cv.weight = (torch.randn(Cout, Cin, 3, 3) / (Cin * 9) ** 0.5).to(dev); cv.bias = torch.zeros(Cout, device=dev)
+cw = _ConvW(cv)
+x = torch.randn(B, H, H, Cin, device=dev)
+res = torch.randn(B, H, H, Cout, device=dev)
+coef = torch.stack([torch.ones(B, Cin, device=dev), torch.zeros(B, Cin, device=dev)], -1).contiguous()
+out = torch.empty(B, H, H, Cout, device=dev)
+part = torch.empty(B, (H // 8) * (H // 16), cw.fnpad // 4, 2, device=dev)
+def run():
+    L.check(lib.lgen_conv_fused(L.ptr(x), 0 if abl & 1 else L.ptr(coef), 0 if abl & 1 else 1, L.ptr(cw.frag), L.ptr(cw.bias), 0 if abl & 2 else L.ptr(res), L.ptr(out), 0 if abl & 4 else L.ptr(part), B, H, H, Cin, Cout,
+                                cw.fnpad, 3, 0, 0, L.stream()), "conv")
+run(); torch.cuda.synchronize(); t = time.time()
+for _ in range(reps): run()
+torch.cuda.synchronize(); dt = (time.time() - t) / reps
+fl = 3 * 2 * 9 * Cin * Cout * H * H * B
+print(f"conv_fused v{variant} abl={abl} B={B} {H}x{H} {Cin}->{Cout}: {dt*1e3:.3f} ms  {fl/dt/1e12:.0f} TFLOP/s (3-pass)")

@@ -195,12 +195,6 @@ int lgen_to_uint8_hwc(const float* in_nchw, unsigned char* out_nhwc, int B, int 
  * the decode chain -- so that the successor starts on a warm memory-side cache.  NULL clears it. */
 int lgen_prefetch_hint(const void* next_weights, long long bytes);
 
-/* Scheduling aid (no reference counterpart): request one dword of every 128-byte line of `rows` byte ranges
- * [base + r*row_stride, +row_bytes) so that the lines move HBM -> memory-side cache.  With len_ptr != NULL the
- * range length is (*len_ptr + 1) * bytes_per_len instead of row_bytes (device-side kv_len = pos + 1). */
-int lgen_touch_lines(const void* base, long long row_bytes, long long row_stride, int rows, const int* len_ptr,
-                     long long bytes_per_len, int blocks, void* stream);
-
 /* ---- tuning knobs (process-wide kernel variant selection; defaults are the measured-best ones) ---- */
 int lgen_set_attn_variant(int v);  /* (K/V loads per buffer, waves per (b,h)): 2 (default) = (2,2); 1 = (2,4); 0 = (4,4); 3 = (4,2); 4 = (2,1); 5 = (4,1) */
 int lgen_set_weight_nt(int v);     /* 0 (default): GEMM weight loads with the default cache policy; 1: non-temporal */

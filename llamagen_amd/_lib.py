@@ -35,7 +35,6 @@ SIGNATURES = {
     "lgen_resize_bicubic": [_P, _P, _I, _I, _I, _I, _I, _P],
     "lgen_to_uint8_hwc": [_P, _P, _I, _I, _I, _I, _P],
     "lgen_prefetch_hint": [_P, _c.c_longlong],
-    "lgen_touch_lines": [_P, _c.c_longlong, _c.c_longlong, _I, _P, _c.c_longlong, _I, _P],
     "lgen_set_attn_variant": [_I],
     "lgen_set_igemm_variant": [_I],
     "lgen_stream_create_cu_mask": [_P, _I, _P],

@@ -666,35 +666,3 @@ extern "C" int lgen_attn_prefill(const void* q_rows, const void* k_cache, const 
     LGEN_CHECK_LAUNCH();
     return 0;
 }
-
-// ---------------------------------------------------------------------------------------------
-// lgen_touch_lines: pull `rows` byte ranges [base + r*row_stride, +row_bytes) towards the memory-side
-// cache (Infinity Cache) by requesting ONE dword of every 128-byte line.  Only 4 bytes per line travel
-// to a CU; the line itself moves HBM -> memory-side cache.  Used to move the KV stream of the NEXT
-// layer's decode attention into the shadow of the (latency-bound, HBM-idle) GEMM kernels of the
-// current layer.  No reference counterpart (scheduling aid, no arithmetic).
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void touch_lines_kernel(const char* __restrict__ base, long long row_bytes,
-                                                          long long row_stride, int rows, const int* __restrict__ len_ptr,
-                                                          long long bytes_per_len) {
-    long long rb = row_bytes;
-    if (len_ptr) rb = (long long)(*len_ptr + 1) * bytes_per_len;   // device-side length (kv_len = pos + 1)
-    const long long lines_per_row = (rb + 127) >> 7;
-    const long long total = lines_per_row * rows;
-    unsigned junk = 0;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const long long r = i / lines_per_row, l = i - r * lines_per_row;
-        const char* p = base + r * row_stride + (l << 7);
-        asm volatile("global_load_dword %0, %1, off" : "+v"(junk) : "v"(p));
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::"v"(junk) : "memory");
-}
-
-extern "C" int lgen_touch_lines(const void* base, long long row_bytes, long long row_stride, int rows, const int* len_ptr,
-                                long long bytes_per_len, int blocks, void* stream) {
-    if (!base || rows < 1 || blocks < 1) return LGEN_ERR_BAD_ARG;
-    hipLaunchKernelGGL(touch_lines_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const char*)base, row_bytes,
-                       row_stride, rows, len_ptr, bytes_per_len);
-    LGEN_CHECK_LAUNCH();
-    return 0;
-}

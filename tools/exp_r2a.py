@@ -1,4 +1,6 @@
-"""Round-2 experiment batch A (development aid; results are quoted in DESIGN.md):
+"""Round-2 experiment batch A (development aid; results are quoted in DESIGN.md).  E1 needs the experimental
+`lgen_touch_lines` kernel, which was removed from the library after the experiment came out negative (git history:
+commit "Headline-config parity tests ..." has it); E2 / E3 run on the current library.
   E1  does the decode attention run faster when its K/V rows were pulled into the memory-side cache first
       (lgen_touch_lines), and what does the pull cost alone / next to a GEMM chain on another stream?
   E2  rows per decode chain x chains in flight (decode only): is a CFG batch better run as two half chains?
@@ -153,7 +155,7 @@ def e2(gpt, grid, tag="E2"):
 
 
 def main():
-    which = sys.argv[1:] or ["e1", "e2", "e3"]
+    which = sys.argv[1:] or ["e2", "e3"]
     gpt = build()
     if "e1" in which:
         try:

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define LGEN_ABI_VERSION 3
+#define LGEN_ABI_VERSION 4
 #define LGEN_BF16 0
 #define LGEN_F32 1
 
@@ -119,6 +119,33 @@ int lgen_sample(const void* logits, const float* noise, long long noise_step_str
                 float temperature, int top_k, float top_p, int greedy, int dtype, void* stream);
 
 int lgen_advance_state(int* state, void* stream);
+
+/* ---- continuous batching (autoregressive/serve/: the vLLM fork's token-level scheduling -- every row of the step batch is its
+ * own request at its own position; serve/sampler.py:54-58,106-108 pairs a conditional and an unconditional sequence per
+ * request).  Same kernels as above with PER-ROW positions: row_pos[m] instead of one device scalar. ---- */
+
+/* lgen_embed_pack with a per-row source: row m at position 0 is a fresh request and takes cls_table[cond[m]] (its prefill
+ * token, gpt.py:348-349), any other row takes tok_table[cur_tok[m]] (gpt.py:351). */
+int lgen_embed_rows(const void* tok_table, const void* cls_table, const int* cur_tok, const int* cond, const int* row_pos,
+                    void* hp, float* ssq_out, int M, int MTs, int d, int tok_rows, int cls_rows, int dtype, void* stream);
+
+/* lgen_gemm_qkv_rope with RoPE angles and the KV-cache slot of row m taken at row_pos[m] ([MTs*16] device ints). */
+int lgen_gemm_qkv_rope_rows(const void* wp, const void* xp, void* q_out, void* k_cache, void* v_cache, const float* freqs,
+                            const int* row_pos, int M, int MTs, int d, int n_head, int hd, int hdp, int S8,
+                            int kv_row_stride, int dtype, int mt, int nt, int kw, const void* norm_w, const float* ssq_in,
+                            int ssq_parts, float eps, void* stream);
+
+/* lgen_attn_decode with kv_len of row b = row_pos[b] + 1. */
+int lgen_attn_decode_rows(const void* q, const void* k_cache, const void* v_cache, void* out_packed, const int* row_pos,
+                          const unsigned char* mask, int mask_len, int B2, int MTs, int n_head, int hd, int hdp, int S8,
+                          int kv_row_stride, int dtype, void* stream);
+
+/* lgen_sample per slot: slot b is at step row_step[b] of max_steps (>= max_steps: empty / finished, skipped); its Exp(1) draws
+ * are noise[(b*max_steps + step)*V ..]; writes seq[b][step], cur_tok[b] (and cur_tok[B+b]), then advances row_step[b] and
+ * row_pos[b] (and row_pos[B+b]). */
+int lgen_sample_rows(const void* logits, const float* noise, int* cur_tok, int* seq, int* row_step, int* row_pos, int max_steps,
+                     int B, int V, int seq_stride, int use_cfg, float cfg_scale, int cfg_interval, float temperature, int top_k,
+                     float top_p, int greedy, int dtype, void* stream);
 
 /* ---- VQ-VAE tokenizer (tokenizer/tokenizer_image/vq_model.py), fp32 NHWC activations ------------- */
 

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblgen_hip.so")
 BF16, F32 = 0, 1
 EPI_ROWS, EPI_PACKED, EPI_GELU, EPI_RES, EPI_SWIGLU, EPI_QKV = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 3
+ABI_VERSION = 4
 ERR_UNSUPPORTED = -2
 
 _c = ctypes
@@ -47,6 +47,10 @@ SIGNATURES = {
     "lgen_attn_prefill": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "lgen_sample": [_P, _P, _c.c_longlong, _P, _P, _P, _I, _I, _I, _I, _F, _I, _F, _I, _F, _I, _I, _P],
     "lgen_advance_state": [_P, _P],
+    "lgen_embed_rows": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "lgen_gemm_qkv_rope_rows": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _F, _P],
+    "lgen_attn_decode_rows": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "lgen_sample_rows": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _F, _I, _F, _I, _I, _P],
     "lgen_vq_codebook_prep": [_P, _P, _P, _I, _I, _I, _P],
     "lgen_vq_lookup_pqconv": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "lgen_vq_argmin": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],

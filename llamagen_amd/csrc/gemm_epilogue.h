@@ -13,7 +13,8 @@ struct GemmArgs {
     void* kc;            // QKV: k cache
     void* vc;            // QKV: v cache
     const float* freqs;  // QKV: [P][hd/2][2] fp32 (cos, sin)
-    const int* pos_ptr;  // QKV: device scalar, position of this token
+    const int* pos_ptr;  // QKV: position of this token: device scalar, or one per row (pos_stride = 1)
+    int pos_stride;      // QKV: 0 = all rows at *pos_ptr; 1 = row m at pos_ptr[m] (continuous batching: every row its own position)
     const uint4* nw;     // NORM: RMSNorm weight [K] storage dtype
     const float* ssq_in; // NORM: [parts][MTs*16] partial sums of squares of the x rows
     float* ssq_out;      // RES: [N/16][MTs*16] partial sums of squares of the new rows (nullable)
@@ -77,6 +78,7 @@ LGEN_DEV uint4 epi_prefetch(const GemmArgs& a, int nt, int mt, int lane, int pos
             aux = *(const uint4*)((const float*)a.out + o);
         }
     } else if constexpr (EPI == EPI_QKV) {
+        if (a.pos_stride) pos = a.pos_ptr[(mt * 16 + r) * a.pos_stride];
         const int sec = n / a.d;
         if (sec < 2) {
             const int c = n - sec * a.d;
@@ -125,6 +127,7 @@ LGEN_DEV void epilogue(const GemmArgs& a, int nt, int mt, int lane, f32x4_t v, f
                D::rnd(silu_f(x0)) * y0, D::rnd(silu_f(x1)) * y1, D::rnd(silu_f(x2)) * y2, D::rnd(silu_f(x3)) * y3);
     } else if constexpr (EPI == EPI_QKV) {
         if (m >= a.M) return;
+        if (a.pos_stride) pos = a.pos_ptr[m * a.pos_stride];
         const int sec = n / a.d;
         const int c = n - sec * a.d;
         const int head = c / a.hd;

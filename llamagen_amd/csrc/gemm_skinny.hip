@@ -317,15 +317,16 @@ extern "C" int lgen_gemm(const void* wp, const void* xp, void* out, int M, int M
     }
 }
 
-extern "C" int lgen_gemm_qkv_rope(const void* wp, const void* xp, void* q_out, void* k_cache, void* v_cache,
-                                  const float* freqs, const int* pos_ptr, int M, int MTs, int d, int n_head, int hd,
-                                  int hdp, int S8, int kv_row_stride, int dtype, int mt, int nt, int kw,
-                                  const void* norm_w, const float* ssq_in, int ssq_parts, float eps, void* stream) {
+static int qkv_rope_impl(const void* wp, const void* xp, void* q_out, void* k_cache, void* v_cache, const float* freqs,
+                         const int* pos_ptr, int pos_stride, int M, int MTs, int d, int n_head, int hd, int hdp, int S8,
+                         int kv_row_stride, int dtype, int mt, int nt, int kw, const void* norm_w, const float* ssq_in,
+                         int ssq_parts, float eps, void* stream) {
     const int kcsz = dtype == LGEN_BF16 ? 32 : 16;
-    if (d % kcsz || (3 * d) % 16 || hd % 4 || d != n_head * hd || M > MTs * 16) return LGEN_ERR_BAD_ARG;
+    if (d % kcsz || (3 * d) % 16 || hd % 4 || d != n_head * hd || M > MTs * 16 || pos_stride < 0 || pos_stride > 1)
+        return LGEN_ERR_BAD_ARG;
     GemmArgs a{};
     a.wp = (const uint4*)wp; a.xp = (const uint4*)xp; a.out = q_out; a.kc = k_cache; a.vc = v_cache;
-    a.freqs = freqs; a.pos_ptr = pos_ptr;
+    a.freqs = freqs; a.pos_ptr = pos_ptr; a.pos_stride = pos_stride;
     a.N = 3 * d; a.KCH = d / kcsz; a.MTs = MTs; a.M = M;
     a.d = d; a.hd = hd; a.hdp = hdp; a.H = n_head; a.S8 = S8;
     a.kvs = kv_row_stride > 0 ? kv_row_stride : hdp;
@@ -334,4 +335,20 @@ extern "C" int lgen_gemm_qkv_rope(const void* wp, const void* xp, void* q_out, v
     lgen_take_prefetch_hint(&a.pf, &a.pf_bytes);
     a.nt = g_weight_nt;
     return dispatch_norm<EPI_QKV>(a, dtype, mt, nt, kw, (hipStream_t)stream);
+}
+
+extern "C" int lgen_gemm_qkv_rope(const void* wp, const void* xp, void* q_out, void* k_cache, void* v_cache,
+                                  const float* freqs, const int* pos_ptr, int M, int MTs, int d, int n_head, int hd,
+                                  int hdp, int S8, int kv_row_stride, int dtype, int mt, int nt, int kw,
+                                  const void* norm_w, const float* ssq_in, int ssq_parts, float eps, void* stream) {
+    return qkv_rope_impl(wp, xp, q_out, k_cache, v_cache, freqs, pos_ptr, 0, M, MTs, d, n_head, hd, hdp, S8, kv_row_stride, dtype,
+                         mt, nt, kw, norm_w, ssq_in, ssq_parts, eps, stream);
+}
+
+extern "C" int lgen_gemm_qkv_rope_rows(const void* wp, const void* xp, void* q_out, void* k_cache, void* v_cache,
+                                       const float* freqs, const int* row_pos, int M, int MTs, int d, int n_head, int hd,
+                                       int hdp, int S8, int kv_row_stride, int dtype, int mt, int nt, int kw,
+                                       const void* norm_w, const float* ssq_in, int ssq_parts, float eps, void* stream) {
+    return qkv_rope_impl(wp, xp, q_out, k_cache, v_cache, freqs, row_pos, 1, M, MTs, d, n_head, hd, hdp, S8, kv_row_stride, dtype,
+                         mt, nt, kw, norm_w, ssq_in, ssq_parts, eps, stream);
 }

@@ -16,7 +16,10 @@
 template <typename D>
 __global__ __launch_bounds__(256) void embed_pack_kernel(const uint4* __restrict__ table, const int* __restrict__ idx,
                                                          uint4* __restrict__ hp, float* __restrict__ ssq_out,
-                                                         int* __restrict__ state, int M, int MTs, int d, int rows) {
+                                                         int* __restrict__ state, int M, int MTs, int d, int rows,
+                                                         const uint4* __restrict__ table0 = nullptr,
+                                                         const int* __restrict__ idx0 = nullptr,
+                                                         const int* __restrict__ row_pos = nullptr, int rows0 = 0) {
     const int KCH = d / D::KC;
     const int total = KCH * MTs * 64;  // a multiple of 64: every wave is one (kc, mt) chunk
     if (state && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -30,9 +33,13 @@ __global__ __launch_bounds__(256) void embed_pack_kernel(const uint4* __restrict
         const int m = mt * 16 + (lane & 15);
         uint4 v = make_uint4(0, 0, 0, 0);
         if (m < M) {
-            int row = idx[m];
-            row = row < 0 ? 0 : (row >= rows ? rows - 1 : row);
-            v = table[((size_t)row * d + kc * D::KC + (lane >> 4) * D::EPL) / D::EPL];
+            // continuous batching: a row at position 0 is a fresh request -> its conditioning embedding (table0[idx0[m]])
+            const bool first = row_pos && row_pos[m] == 0;
+            const uint4* tb = first ? table0 : table;
+            const int nr = first ? rows0 : rows;
+            int row = first ? idx0[m] : idx[m];
+            row = row < 0 ? 0 : (row >= nr ? nr - 1 : row);
+            v = tb[((size_t)row * d + kc * D::KC + (lane >> 4) * D::EPL) / D::EPL];
         }
         hp[t] = v;
         if (ssq_out) {
@@ -60,6 +67,29 @@ extern "C" int lgen_embed_pack(const void* table, const int* idx, void* hp, floa
         int total = (d / 16) * MTs * 64;
         hipLaunchKernelGGL(embed_pack_kernel<F32>, dim3((total + 255) / 256), dim3(256), 0, st, (const uint4*)table, idx,
                            (uint4*)hp, ssq_out, state_advance, M, MTs, d, rows);
+    } else {
+        return LGEN_ERR_BAD_ARG;
+    }
+    LGEN_CHECK_LAUNCH();
+    return 0;
+}
+
+// Continuous batching (autoregressive/serve/: every row of the step batch is its own request at its own position): row m
+// takes cls_table[cond[m]] when row_pos[m] == 0 (the request's prefill token, gpt.py:348-349) and tok_table[cur_tok[m]]
+// otherwise (gpt.py:351); the sampler advances row_pos.
+extern "C" int lgen_embed_rows(const void* tok_table, const void* cls_table, const int* cur_tok, const int* cond,
+                               const int* row_pos, void* hp, float* ssq_out, int M, int MTs, int d, int tok_rows, int cls_rows,
+                               int dtype, void* stream) {
+    if (M > MTs * 16 || d % 32 || !row_pos) return LGEN_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == LGEN_BF16) {
+        int total = (d / 32) * MTs * 64;
+        hipLaunchKernelGGL(embed_pack_kernel<BF16>, dim3((total + 255) / 256), dim3(256), 0, st, (const uint4*)tok_table, cur_tok,
+                           (uint4*)hp, ssq_out, (int*)nullptr, M, MTs, d, tok_rows, (const uint4*)cls_table, cond, row_pos, cls_rows);
+    } else if (dtype == LGEN_F32) {
+        int total = (d / 16) * MTs * 64;
+        hipLaunchKernelGGL(embed_pack_kernel<F32>, dim3((total + 255) / 256), dim3(256), 0, st, (const uint4*)tok_table, cur_tok,
+                           (uint4*)hp, ssq_out, (int*)nullptr, M, MTs, d, tok_rows, (const uint4*)cls_table, cond, row_pos, cls_rows);
     } else {
         return LGEN_ERR_BAD_ARG;
     }
@@ -200,6 +230,7 @@ struct AttnArgs {
     const void* vc;
     void* out;           // packed [d/KC][MTs][64][EPL]
     const int* pos_ptr;
+    int pos_stride;      // 0: every row at *pos_ptr; 1: row b at pos_ptr[b] (continuous batching)
     const unsigned char* mask;  // null (pure causal) or causal_mask [B2][S8][S8] bytes: row `pos` is read
     int H, hd, hdp, S8, MTs;
     float sf;            // sqrt(1/sqrt(hd))
@@ -243,7 +274,7 @@ __global__ __launch_bounds__(64 * ATT_NW, (ATT_CH <= 2 ? 4 : 2)) void attn_decod
     int g = wv;
     const uint4 qv = ((const uint4*)a.q)[((size_t)b * a.H + h) * lpr + part];
     ATT_LOAD(k0, v0, g);
-    const int pos = *a.pos_ptr;
+    const int pos = a.pos_ptr[b * a.pos_stride];
     const int kvlen = pos + 1;
     const int ngroups = (kvlen + GK - 1) / GK;
     float qf[EPL];
@@ -337,10 +368,10 @@ static int g_kv_nt = 1;
 extern "C" int lgen_set_kv_nt(int v) { g_kv_nt = v ? 1 : 0; return 0; }
 extern "C" int lgen_set_attn_variant(int v) { g_attn_variant = v; return 0; }
 
-extern "C" int lgen_attn_decode(const void* q, const void* k_cache, const void* v_cache, void* out_packed,
-                                const int* pos_ptr, const unsigned char* mask, int mask_len, int B2, int MTs,
-                                int n_head, int hd, int hdp, int S8, int kv_row_stride, int dtype, void* stream) {
-    AttnArgs a{q, k_cache, v_cache, out_packed, pos_ptr, mask, n_head, hd, hdp, S8, MTs, 0.f,
+static int attn_decode_impl(const void* q, const void* k_cache, const void* v_cache, void* out_packed,
+                            const int* pos_ptr, int pos_stride, const unsigned char* mask, int mask_len, int B2, int MTs,
+                            int n_head, int hd, int hdp, int S8, int kv_row_stride, int dtype, void* stream) {
+    AttnArgs a{q, k_cache, v_cache, out_packed, pos_ptr, pos_stride, mask, n_head, hd, hdp, S8, MTs, 0.f,
                kv_row_stride > 0 ? kv_row_stride : hdp, g_kv_nt, mask_len > 0 ? mask_len : S8, nullptr, 0};
     lgen_take_prefetch_hint(&a.pf, &a.pf_bytes);
     a.sf = sqrtf(1.0f / sqrtf((float)hd));
@@ -368,6 +399,20 @@ extern "C" int lgen_attn_decode(const void* q, const void* k_cache, const void* 
 #undef LGEN_ATT
     LGEN_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int lgen_attn_decode(const void* q, const void* k_cache, const void* v_cache, void* out_packed,
+                                const int* pos_ptr, const unsigned char* mask, int mask_len, int B2, int MTs,
+                                int n_head, int hd, int hdp, int S8, int kv_row_stride, int dtype, void* stream) {
+    return attn_decode_impl(q, k_cache, v_cache, out_packed, pos_ptr, 0, mask, mask_len, B2, MTs, n_head, hd, hdp, S8,
+                            kv_row_stride, dtype, stream);
+}
+
+extern "C" int lgen_attn_decode_rows(const void* q, const void* k_cache, const void* v_cache, void* out_packed,
+                                     const int* row_pos, const unsigned char* mask, int mask_len, int B2, int MTs,
+                                     int n_head, int hd, int hdp, int S8, int kv_row_stride, int dtype, void* stream) {
+    return attn_decode_impl(q, k_cache, v_cache, out_packed, row_pos, 1, mask, mask_len, B2, MTs, n_head, hd, hdp, S8,
+                            kv_row_stride, dtype, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

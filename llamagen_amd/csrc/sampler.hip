@@ -32,6 +32,12 @@ struct SampleArgs {
     int B, V, seq_stride, use_cfg;
     float cfg_scale, temperature, top_p;
     int cfg_interval, top_k, greedy;
+    // continuous batching (all null / 0 otherwise): slot b is its own request at step row_step[b] of max_steps; its noise block
+    // is noise[(b * max_steps + step) * V ...]; a finished / empty slot (step >= max_steps) is skipped; after sampling the
+    // slot's step and the positions of its (cond, uncond) rows advance
+    int* row_step;         // [B]
+    int* row_pos;          // [2B or B]
+    int max_steps;
 };
 
 // Ownership: thread t owns the 8 consecutive vocabulary entries of slot s at i = (s*1024 + t)*8
@@ -125,7 +131,8 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(SampleArgs a) {
     __shared__ unsigned sh_key;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int b = blockIdx.x, V = a.V, B = a.B;
-    const int step = a.state[1];
+    const int step = a.row_step ? a.row_step[b] : a.state[1];
+    if (a.row_step && step >= a.max_steps) return;  // empty / finished slot (uniform over the workgroup)
     // generate.py:113-114: decode iteration i = step-1 drops guidance once i > cfg_interval
     const bool mix = a.use_cfg && !(step > 0 && a.cfg_interval > -1 && (step - 1) > a.cfg_interval);
     const float tdiv = fmaxf(a.temperature, 1e-5f);
@@ -141,7 +148,8 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(SampleArgs a) {
         D::ld8(a.logits, (size_t)b * V + ic, l[s]);
         if (mix) D::ld8(a.logits, (size_t)(B + b) * V + ic, lu[s]);
         if (!a.greedy) {
-            const float4* np = (const float4*)(a.noise + (size_t)step * a.noise_stride + (size_t)b * V + ic);
+            const float4* np = a.row_step ? (const float4*)(a.noise + ((size_t)b * a.max_steps + step) * V + ic)
+                                          : (const float4*)(a.noise + (size_t)step * a.noise_stride + (size_t)b * V + ic);
             const float4 n0 = np[0], n1 = np[1];
             nz[s][0] = n0.x; nz[s][1] = n0.y; nz[s][2] = n0.z; nz[s][3] = n0.w;
             nz[s][4] = n1.x; nz[s][5] = n1.y; nz[s][6] = n1.z; nz[s][7] = n1.w;
@@ -415,6 +423,11 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(SampleArgs a) {
         a.cur_tok[b] = bi;
         if (a.use_cfg) a.cur_tok[B + b] = bi;
         a.seq[(size_t)b * a.seq_stride + step] = bi;
+        if (a.row_step) {
+            a.row_step[b] = step + 1;
+            a.row_pos[b] += 1;
+            if (a.use_cfg) a.row_pos[B + b] += 1;
+        }
     }
 }
 
@@ -424,14 +437,14 @@ __global__ void advance_state_kernel(int* state) {
     state[1] += 1;
 }
 
-extern "C" int lgen_sample(const void* logits, const float* noise, long long noise_step_stride, int* cur_tok, int* seq,
-                           const int* state, int B, int V, int seq_stride, int use_cfg, float cfg_scale,
-                           int cfg_interval, float temperature, int top_k, float top_p, int greedy, int dtype,
-                           void* stream) {
+static int sample_impl(const void* logits, const float* noise, long long noise_step_stride, int* cur_tok, int* seq,
+                       const int* state, int B, int V, int seq_stride, int use_cfg, float cfg_scale,
+                       int cfg_interval, float temperature, int top_k, float top_p, int greedy, int dtype,
+                       int* row_step, int* row_pos, int max_steps, void* stream) {
     if (V > SMP_MAXV || V < 8 || (V & 7) || B < 1) return LGEN_ERR_BAD_ARG;
     if (!greedy && !noise) return LGEN_ERR_BAD_ARG;
     SampleArgs a{logits, noise, noise_step_stride, cur_tok, seq, state, B, V, seq_stride, use_cfg, cfg_scale,
-                 temperature, top_p, cfg_interval, top_k, greedy};
+                 temperature, top_p, cfg_interval, top_k, greedy, row_step, row_pos, max_steps};
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = (size_t)SMP_MAXV * sizeof(float);
     static bool attr_set = false;
@@ -452,6 +465,25 @@ extern "C" int lgen_sample(const void* logits, const float* noise, long long noi
         return LGEN_ERR_BAD_ARG;
     LGEN_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int lgen_sample(const void* logits, const float* noise, long long noise_step_stride, int* cur_tok, int* seq,
+                           const int* state, int B, int V, int seq_stride, int use_cfg, float cfg_scale,
+                           int cfg_interval, float temperature, int top_k, float top_p, int greedy, int dtype,
+                           void* stream) {
+    return sample_impl(logits, noise, noise_step_stride, cur_tok, seq, state, B, V, seq_stride, use_cfg, cfg_scale, cfg_interval,
+                       temperature, top_k, top_p, greedy, dtype, nullptr, nullptr, 0, stream);
+}
+
+// Continuous batching form (autoregressive/serve/sampler.py:54-58,106-108: paired cond / uncond sequences, every request at its
+// own step): slot b samples step row_step[b] < max_steps with noise[(b*max_steps + step)*V ..], writes seq[b][step] and
+// cur_tok[b] (and cur_tok[B+b]), then advances row_step[b] and row_pos[b] (and row_pos[B+b]); other slots are left alone.
+extern "C" int lgen_sample_rows(const void* logits, const float* noise, int* cur_tok, int* seq, int* row_step, int* row_pos,
+                                int max_steps, int B, int V, int seq_stride, int use_cfg, float cfg_scale, int cfg_interval,
+                                float temperature, int top_k, float top_p, int greedy, int dtype, void* stream) {
+    if (!row_step || !row_pos || max_steps < 1) return LGEN_ERR_BAD_ARG;
+    return sample_impl(logits, noise, 0, cur_tok, seq, nullptr, B, V, seq_stride, use_cfg, cfg_scale, cfg_interval, temperature,
+                       top_k, top_p, greedy, dtype, row_step, row_pos, max_steps, stream);
 }
 
 extern "C" int lgen_advance_state(int* state, void* stream) {

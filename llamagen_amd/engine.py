@@ -173,6 +173,7 @@ class DecodeEngine:
         self._force_causal = False  # whole-sequence `is_causal` forward (gpt.py:234) ignores causal_mask
         self._graphs = {}
         self._prof = None
+        self.pos_rows = None         # continuous batching (llamagen_amd/serve.py): int32 [MTs*16] per-row positions
         # RMSNorm folded into the consumer GEMMs (5 launches / layer instead of 7).  Pays off (-12 % step time,
         # GPT-L) only with gemm_normpre.hip, which normalises the activation panel in registers while the
         # weight loads are in flight and needs a wave's K range to fit in registers: bf16, d/32 = 8 waves x
@@ -278,7 +279,11 @@ class DecodeEngine:
         epilogues of the GEMMs that produce the residual stream)."""
         lib, st, dt, M, mts = self.lib, L.stream(), self.dt, self.B2, self.MTs
         d, F, H, hd, hdp, S8 = self.d, self.F, self.H, self.hd, self.hdp, self.S8
-        pos_ptr = self.state.data_ptr()
+        # one device scalar (generate(): all rows at the same position) or one position per row (serve.py)
+        rows = self.pos_rows is not None
+        pos_ptr = self.pos_rows.data_ptr() if rows else self.state.data_ptr()
+        qkv_fn = lib.lgen_gemm_qkv_rope_rows if rows else lib.lgen_gemm_qkv_rope
+        attn_fn = lib.lgen_attn_decode_rows if rows else lib.lgen_attn_decode
         fuse = self.fuse_norm
         tq, to, t13, t2, th = (self._tiles("qkv", 3 * d, d), self._tiles("wo", d, d), self._tiles("w13", 2 * F, d),
                                self._tiles("w2", d, F), self._tiles("head", self.V, d))
@@ -296,16 +301,16 @@ class DecodeEngine:
             else:
                 L.check(lib.lgen_rmsnorm(L.ptr(self.hp), L.ptr(w["an"]), L.ptr(self.xnp), mts, d, self.eps, dt, st), "rmsnorm")
                 x_in, nw = self.xnp, None
-            L.check(lib.lgen_gemm_qkv_rope(L.ptr(w["wqkv"]), L.ptr(x_in), L.ptr(self.qbuf), L.ptr(self.k_cache[i]),
-                                           L.ptr(self.v_cache[i]), L.ptr(self.freqs_cis), pos_ptr, M, mts, d, H, hd, hdp,
-                                           S8, self.kvs, dt, tq[0], tq[1], tq[2], L.ptr(nw), L.ptr(ssq), self.ssq_parts, self.eps, st),
+            L.check(qkv_fn(L.ptr(w["wqkv"]), L.ptr(x_in), L.ptr(self.qbuf), L.ptr(self.k_cache[i]),
+                           L.ptr(self.v_cache[i]), L.ptr(self.freqs_cis), pos_ptr, M, mts, d, H, hd, hdp,
+                           S8, self.kvs, dt, tq[0], tq[1], tq[2], L.ptr(nw), L.ptr(ssq), self.ssq_parts, self.eps, st),
                     "gemm_qkv_rope")
             if self._prof is not None:  # bench.py roofline leg: HIP events on the launch stream
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
             hint(w["wo"])
-            L.check(lib.lgen_attn_decode(L.ptr(self.qbuf), L.ptr(self.k_cache[i]), L.ptr(self.v_cache[i]), L.ptr(self.ap),
-                                         pos_ptr, L.ptr(pm), self.T if pm is not None else 0, M, mts, H, hd, hdp, S8, self.kvs, dt, st), "attn_decode")
+            L.check(attn_fn(L.ptr(self.qbuf), L.ptr(self.k_cache[i]), L.ptr(self.v_cache[i]), L.ptr(self.ap),
+                            pos_ptr, L.ptr(pm), self.T if pm is not None else 0, M, mts, H, hd, hdp, S8, self.kvs, dt, st), "attn_decode")
             if self._prof is not None:
                 e1.record()
                 self._prof["events"].append((e0, e1))

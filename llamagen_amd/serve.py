@@ -1,0 +1,132 @@
+"""Token-level continuous batching of class-conditional sampling on the HIP engine.
+
+What it stands in for: the reference's vLLM fork (autoregressive/serve/llm.py:22-267 request queue + engine loop,
+serve/sampler.py:54-58,106-108 paired conditional / unconditional sequences with CFG applied at sampling time,
+serve/model_runner.py:36-41,982-1076 graph replay over a fixed batch).  Same idea, MI355X-native form:
+
+  * a fixed number of SLOTS; slot b owns rows b (conditional) and B + b (unconditional) of the step batch, its own KV-cache
+    rows and its own Exp(1) noise block -- nothing of one request touches another's rows;
+  * ONE captured hipGraph per step batch: embed (per-row source) -> L x [norm+wqkv+RoPE+append | attention | wo | norm+w1,w3 |
+    w2] -> norm+lm_head -> sample, all with PER-ROW positions (`row_pos`, device ints): a row at position 0 is a fresh
+    request and takes its class embedding, any other row continues with the token it sampled in the previous step;
+  * the host refills finished slots between replays (a handful of scalar writes per new request, no device sync: a request
+    that entered at replay k is complete after replay k + N - 1, which the host knows without asking the GPU).
+
+Every request produces exactly the tokens a batch-of-one `generate()` would with the same noise: rows are independent
+through every kernel (tests/test_gpu_serve.py holds that to the oracle, token for token, in fp32).
+"""
+from __future__ import annotations
+
+import collections
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib as L
+from .engine import DecodeEngine
+from .gpt import find_multiple
+
+
+class ContinuousBatcher:
+    def __init__(self, model, slots: int, max_new_tokens: int, cfg_scale: float = 1.0, cfg_interval: int = -1,
+                 temperature: float = 1.0, top_k: int = 0, top_p: float = 1.0, sample_logits: bool = True):
+        if model.model_type != "c2i":
+            raise NotImplementedError("continuous batching is built for class-conditional models (one prefill token per request)")
+        dev = model.tok_embeddings.weight.device
+        if dev.type != "cuda":
+            raise RuntimeError("llamagen_amd.serve runs only on an AMD GPU through the HIP library (no CPU fallback)")
+        self.model, self.dev = model, dev
+        self.B, self.N = slots, max_new_tokens
+        self.use_cfg = cfg_scale > 1.0
+        self.B2 = 2 * slots if self.use_cfg else slots
+        dtype = model.tok_embeddings.weight.dtype
+        self.S8 = find_multiple(1 + max_new_tokens, 8)
+        if max_new_tokens > model.block_size:
+            raise IndexError(f"{max_new_tokens} tokens exceed block_size {model.block_size}")
+        self.eng = DecodeEngine(model, self.B2, self.S8, dtype)
+        e = self.eng
+        R = e.MTs * 16
+        self.row_pos = torch.full((R,), max_new_tokens, dtype=torch.int32, device=dev)   # parked rows sit on a valid slot
+        self.row_step = torch.full((slots,), max_new_tokens, dtype=torch.int32, device=dev)  # >= N: empty slot
+        self.cond = torch.full((R,), model.num_classes, dtype=torch.int32, device=dev)      # uncond rows: the null class
+        self.noise = torch.empty(slots, max_new_tokens, e.V, dtype=torch.float32, device=dev) if sample_logits else None
+        self.seq = torch.zeros(slots, max_new_tokens, dtype=torch.int32, device=dev)
+        self.sp = dict(cfg_scale=float(cfg_scale), cfg_interval=int(cfg_interval), temperature=float(temperature), top_k=int(top_k),
+                       top_p=float(top_p), greedy=0 if sample_logits else 1)
+        e.pos_rows = self.row_pos  # switches the engine's layer chain to the per-row entry points
+        self._graph = None
+        self._queue = collections.deque()
+        self._slot_req: List[Optional[int]] = [None] * slots
+        self._slot_left = [0] * slots
+        self._next_id = 0
+        self.steps_run = 0
+
+    # ---- requests ---------------------------------------------------------------------------------------------------
+    def submit(self, class_label: int, noise: Optional[torch.Tensor] = None) -> int:
+        """Queue one image request; `noise` (optional, [N, V] fp32 Exp(1) draws) replaces the default generator's draw."""
+        rid = self._next_id
+        self._next_id += 1
+        self._queue.append((rid, int(class_label), noise))
+        return rid
+
+    def _load(self, b: int, rid: int, label: int, noise):
+        """Slot b <- a fresh request: position / step 0, its class label, its noise block (stream-ordered scalar writes)."""
+        self.row_pos[b] = 0
+        self.row_step[b] = 0
+        self.cond[b] = label
+        if self.use_cfg:
+            self.row_pos[self.B + b] = 0
+        if self.noise is not None:
+            if noise is not None:
+                self.noise[b].copy_(noise.to(self.dev))
+            else:
+                self.noise[b].exponential_(1.0)
+        self._slot_req[b], self._slot_left[b] = rid, self.N
+
+    # ---- one step of the whole slot batch -------------------------------------------------------------------------------
+    def _step(self):
+        e, lib, sp = self.eng, self.eng.lib, self.sp
+        L.check(lib.lgen_embed_rows(L.ptr(e.tok_emb), L.ptr(e.cls_emb), L.ptr(e.cur_tok), L.ptr(self.cond), L.ptr(self.row_pos),
+                                    L.ptr(e.hp), L.ptr(e.ssq) if e.fuse_norm else 0, self.B2, e.MTs, e.d, e.tok_emb.shape[0],
+                                    e.cls_emb.shape[0], e.dt, L.stream()), "embed_rows")
+        e.ssq_parts = e.d // e.kc
+        e._layers_and_logits()
+        L.check(lib.lgen_sample_rows(L.ptr(e.logits), L.ptr(self.noise), L.ptr(e.cur_tok), L.ptr(self.seq), L.ptr(self.row_step),
+                                     L.ptr(self.row_pos), self.N, self.B, e.V, self.N, 1 if self.use_cfg else 0, sp["cfg_scale"],
+                                     sp["cfg_interval"], sp["temperature"], sp["top_k"], sp["top_p"], sp["greedy"], e.dt, L.stream()),
+                "sample_rows")
+
+    def run(self, use_graph: bool = True) -> Dict[int, torch.Tensor]:
+        """Drain the queue; returns {request id: int32 [N] token ids} (device tensors, enqueued on the current stream)."""
+        done: Dict[int, torch.Tensor] = {}
+        with torch.no_grad():
+            while self._queue or any(r is not None for r in self._slot_req):
+                for b in range(self.B):  # refill free slots (arrival order)
+                    if self._slot_req[b] is None and self._queue:
+                        self._load(b, *self._queue.popleft())
+                if use_graph:
+                    if self._graph is None:
+                        self._step()  # warm every kernel once, eagerly
+                        self.steps_run += 1
+                        self._account(done)
+                        g = torch.cuda.CUDAGraph()
+                        torch.cuda.synchronize()
+                        with torch.cuda.graph(g):
+                            self._step()
+                        self._graph = g
+                        continue
+                    self._graph.replay()
+                else:
+                    self._step()
+                self.steps_run += 1
+                self._account(done)
+        return done
+
+    def _account(self, done):
+        for b in range(self.B):
+            if self._slot_req[b] is None:
+                continue
+            self._slot_left[b] -= 1
+            if self._slot_left[b] == 0:  # the step just enqueued wrote this request's last token
+                done[self._slot_req[b]] = self.seq[b].clone()
+                self._slot_req[b] = None

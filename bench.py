@@ -255,6 +255,8 @@ def main():
     ap.add_argument("--steps-per-turn", type=int, default=1, help="decode steps a lane enqueues per scheduler turn")
     ap.add_argument("--vq-own-stream", action="store_true", help="decode images on a separate shared stream (measured slower)")
     ap.add_argument("--lane-cu-mask", action="store_true", help="experiment: every lane's stream owns 1/lanes of the CUs")
+    ap.add_argument("--vq-cus", type=int, default=0, help="experiment: confine the VQ decoder to this many CUs (one masked stream)")
+    ap.add_argument("--lanes-avoid-vq-cus", action="store_true", help="experiment: with --vq-cus, keep the decode lanes off those CUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -279,7 +281,8 @@ def main():
         T = {0: 0.0, 1: 1.0, 2: 1.44, 3: 2.02}
         args.lanes = min((1, 2, 3), key=lambda l: (args.steps // l) * T[l] + T[args.steps % l])
     pipe = SamplingPipeline(gpt, vq, lanes=args.lanes, steps_per_turn=args.steps_per_turn, vq_low_priority=args.vq_own_stream,
-                            cu_partition=True if args.lane_cu_mask else None)
+                            cu_partition=True if args.lane_cu_mask else None, vq_cus=args.vq_cus,
+                            lanes_avoid_vq_cus=args.lanes_avoid_vq_cus)
     pipe.prepare(BATCH, N, **skw)  # setup (like loading weights): KV slabs, workspaces, decode graphs per lane
     torch.cuda.synchronize()
 

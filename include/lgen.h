@@ -3,9 +3,15 @@
  * The reference (FoundationVision/LlamaGen) has no native/FFI layer on this path: the boundary a
  * replacement sits behind is its Python API.  This header is the C ABI
  * underneath our Python host mirror (llamagen_amd/): `extern "C"`, raw device pointers + sizes,
- * a `hipStream_t` passed as void*, no torch types, no allocation, no synchronisation, no global
- * mutable state; every entry point only enqueues kernels on the given stream (hipGraph-capture
- * safe) and returns 0 or a hipError_t / LGEN_ERR_* code.  Each entry point cites the reference
+ * a `hipStream_t` passed as void*, no torch types, no allocation, no synchronisation; every entry
+ * point only enqueues kernels on the given stream (hipGraph-capture safe) and returns 0 or a
+ * hipError_t / LGEN_ERR_* code.  State held inside the library, all of it process-wide and none of
+ * it data: (1) the kernel-variant / cache-policy selectors of the "tuning knobs" section below
+ * (lgen_set_*: plain ints read at launch time -- set them before the first launch, not concurrently
+ * with launches from another thread; a captured graph keeps the variant it was captured with),
+ * (2) one-shot `hipFuncSetAttribute` flags for the kernels that need more than 64 KiB of LDS (set on
+ * first use for the current device; a process that drives several devices from one thread should
+ * make one warm-up call per device), (3) the per-thread, one-shot lgen_prefetch_hint.  Each entry point cites the reference
  * op sequence it replaces (paths relative to the reference repository root).
  *
  * Fragment-packed layouts ("chunk" = 1 KiB = [16 rows][KC k] in MFMA operand order, lane =

@@ -107,10 +107,19 @@ class SamplingPipeline:
     results are enqueued-behind on the CURRENT stream when run() returns (no host synchronisation)."""
 
     def __init__(self, gpt, vq=None, lanes: int = 2, steps_per_turn: int = 1, vq_low_priority: bool = False,
-                 cu_partition: Optional[bool] = None):
+                 cu_partition: Optional[bool] = None, vq_cus: int = 0, lanes_avoid_vq_cus: bool = False):
         self.dev = next(gpt.parameters()).device
         # optional: one shared stream for every lane's VQ decode (see SamplingLane)
         self.vq_stream = torch.cuda.Stream(device=self.dev, priority=0) if (vq is not None and vq_low_priority) else None
+        # experiment (bench.py --vq-cus N): the MFMA-bound decoder kernels fill the register file of every CU they run on
+        # (2 x 256 threads x 186 VGPRs), so nothing of the decode lanes co-resides with them; confining the decoder to N
+        # CUs (one shared, CU-masked stream) leaves the other CUs to the latency-bound decode chains
+        n_cu = torch.cuda.get_device_properties(self.dev).multi_processor_count if torch.cuda.is_available() else 256
+        if vq is not None and vq_cus > 0:
+            words = [0] * ((n_cu + 31) // 32)
+            for b in range(min(vq_cus, n_cu)):
+                words[b // 32] |= 1 << (b % 32)
+            self.vq_stream = masked_stream(self.dev, words)
         lanes = max(1, lanes)
         # optional (experiment, LGEN_LANE_CU_MASK=1): every lane's stream owns 1/lanes of the CUs, so that the lanes'
         # kernels run side by side on disjoint CUs instead of each launch spreading over the whole chip.  Measured
@@ -119,8 +128,12 @@ class SamplingPipeline:
         if cu_partition is None:
             cu_partition = os.environ.get("LGEN_LANE_CU_MASK", "0") == "1"
         streams = [None] * lanes
+        if lanes_avoid_vq_cus and vq_cus > 0:
+            words = [0] * ((n_cu + 31) // 32)
+            for b in range(vq_cus, n_cu):
+                words[b // 32] |= 1 << (b % 32)
+            streams = [masked_stream(self.dev, words) for _ in range(lanes)]
         if cu_partition and lanes > 1:
-            n_cu = torch.cuda.get_device_properties(self.dev).multi_processor_count
             streams = [masked_stream(self.dev, cu_mask_words(n_cu, i, lanes)) for i in range(lanes)]
         self.cu_partition = bool(cu_partition and lanes > 1)
         self.lanes: List[SamplingLane] = [SamplingLane(gpt, vq, stream=streams[i], primary=(i == 0), vq_stream=self.vq_stream)

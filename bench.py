@@ -389,9 +389,25 @@ def main():
             torch.cuda.synchronize()
             vq_ms = e0.elapsed_time(e1) / 3
             tf = 3 * 570.1e9 * BATCH / (vq_ms * 1e-3) / 1e12
-            res["roofline_vq_decode"] = {"bound": "mfma", "kernel": "igemm_kernel (+ GroupNorm/split passes)", "achieved": round(tf, 1),
-                                         "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
-                                         "ms_per_decode_code": round(vq_ms, 2), "flop_per_image_fp32": 570.1e9, "mfma_passes": 3}
+            # context for the fraction: what the vendor library's tuned bf16 GEMM reaches on THIS chip on random operands (the
+            # chip clocks to its power budget: 1.19-1.27 PF measured, 1.5-1.7 PF on all-zero operands) -- the practical dense ceiling
+            n = 8192
+            ga, gb = torch.randn(n, n, device=dev).bfloat16(), torch.randn(n, n, device=dev).bfloat16()
+            for _ in range(3):
+                gc = ga @ gb
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                gc = ga @ gb
+            e1.record()
+            torch.cuda.synchronize()
+            lib_tf = 2 * n ** 3 * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e12
+            del ga, gb, gc
+            res["roofline_vq_decode"] = {"bound": "mfma", "kernel": "conv_fused_kernel (GroupNorm/swish/split fused) + igemm_kernel at 24x24",
+                                         "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
+                                         "ms_per_decode_code": round(vq_ms, 2), "flop_per_image_fp32": 570.1e9, "mfma_passes": 3,
+                                         "hipblaslt_bf16_gemm_8192_random_TFLOPs": round(lib_tf, 1),
+                                         "frac_of_that_measured_ceiling": round(tf / lib_tf, 4)}
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only (the other ranks would idle in the barrier)
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)

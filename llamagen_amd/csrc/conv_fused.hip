@@ -48,7 +48,13 @@ LGEN_DEV void split8(const float (&f)[8], uint4& hi, uint4& lo) {
     lo = BF16::pack(r);
 }
 
-template <int JN, int WNW, int KS, int NWV>
+template <int N>
+LGEN_DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// DMA = true: the weight tiles go HBM/L2 -> LDS directly (`global_load_lds_dwordx4`, one 1 KiB fragment per wave-instruction; the
+// fragment-packed global layout IS the LDS image), issued right after a step's fragment reads and waited for before the step's
+// closing barrier: no staging registers, no ds_write pass.
+template <int JN, int WNW, int KS, int NWV, bool DMA>
 __global__ __launch_bounds__(64 * NWV, NWV / 2) void conv_fused_kernel(ConvFArgs a) {
     constexpr int PAD = KS / 2, TH = 8, TW = 16, TAPS = KS * KS, NT = 64 * NWV;  // NT threads, NWV waves (2 workgroups / CU)
     constexpr int WMW = NWV / WNW, JM = TH / WMW;
@@ -172,7 +178,50 @@ __global__ __launch_bounds__(64 * NWV, NWV / 2) void conv_fused_kernel(ConvFArgs
 #pragma unroll
         for (int i = 0; i < JM; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+    int kc = 0, tap = 0;
     const int fr = lane & 15, fg = lane >> 4;
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    auto dma_w = [&](int step_, int buf_) {  // weight tile of `step_` -> LDS buffer `buf_`, one fragment per wave-instruction
+        if (step_ < nsteps) {
+            const uint4* src = wbase + (size_t)step_ * (WT / 16) + lane;
+#pragma unroll
+            for (int i = 0; i < (WT / 1024 + NWV - 1) / NWV; ++i) {
+                const int c = wv + i * NWV;
+                if ((WT / 1024) % NWV == 0 || c < WT / 1024)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(src + c * 64), (lptr_t)(sW + buf_ * WT + c * 1024), 16, 0, 0);
+            }
+        }
+    };
+    // DMA form of one step: ALL fragment reads first, then the next step's weight DMA (+ the next chunk's halo loads on the
+    // first tap: issued after the DMA so that the counted wait below covers the DMA only), then the MFMAs
+    auto compute_dma = [&](int wbuf, int tap, int s, bool halo_next) {
+        const int ty = tap / KS, tx = tap - ty * KS;
+        const unsigned char* hb = sH + fg * FGS + (size_t)((wm * JM + ty) * HC + fr + tx) * 16;
+        uint4 phi[JM], plo[JM], wh[JN], wl[JN];
+#pragma unroll
+        for (int i = 0; i < JM; ++i) {
+            phi[i] = *(const uint4*)(hb + i * HC * 16);
+            plo[i] = *(const uint4*)(hb + PLANE + i * HC * 16);
+        }
+        const unsigned char* wb = sW + wbuf * WT + lane * 16;
+#pragma unroll
+        for (int j = 0; j < JN; ++j) {
+            wh[j] = *(const uint4*)(wb + (wn * JN + j) * 1024);
+            wl[j] = *(const uint4*)(wb + (BN / 16 + wn * JN + j) * 1024);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads above are done before the DMA below may overwrite
+        dma_w(s + 1, wbuf ^ 1);                             // (buffer wbuf^1 was last read one step ago, by every wave)
+        if (halo_next) CF_GLOAD_HALO(kc + 1);
+#pragma unroll
+        for (int j = 0; j < JN; ++j)
+#pragma unroll
+            for (int i = 0; i < JM; ++i) {
+                acc[j][i] = BF16::mma(wl[j], phi[i], acc[j][i]);
+                acc[j][i] = BF16::mma(wh[j], plo[i], acc[j][i]);
+                acc[j][i] = BF16::mma(wh[j], phi[i], acc[j][i]);
+            }
+    };
     auto compute = [&](int wbuf, int tap) {
         const int ty = tap / KS, tx = tap - ty * KS;
         const unsigned char* hb = sH + fg * FGS + (size_t)((wm * JM + ty) * HC + fr + tx) * 16;
@@ -196,11 +245,31 @@ __global__ __launch_bounds__(64 * NWV, NWV / 2) void conv_fused_kernel(ConvFArgs
         }
     };
 
+    if constexpr (DMA) {
+        dma_w(0, 0);
+        CF_GLOAD_HALO(0);
+        for (int s = 0; s < nsteps; ++s) {
+            bool halo_next = false;
+            if (tap == 0) {  // every wave is past the barrier that ended the previous chunk's last tap
+                store_halo();      // (waits for the raw halo loads and, in program order before them, the DMA of this step)
+                __syncthreads();
+                halo_next = kc + 1 < nkc;
+            }
+            compute_dma(s & 1, tap, s, halo_next);
+            // own DMA of step s+1 landed (the halo loads issued after it may stay in flight), then everybody's
+            if (halo_next) {
+                if (a.coef) wait_vmcnt<2 * ITER + 4>(); else wait_vmcnt<2 * ITER>();
+            } else {
+                wait_vmcnt<0>();
+            }
+            __builtin_amdgcn_s_barrier();
+            if (++tap == TAPS) { tap = 0; ++kc; }
+        }
+    } else {
     gload_w(0, wa0, wa1, wa2, wa3);
     CF_GLOAD_HALO(0);
     gload_w(1, wb0, wb1, wb2, wb3);
     lstore_w(0, wa0, wa1, wa2, wa3);
-    int kc = 0, tap = 0;
     // one step = one filter tap of one 32-channel chunk; LD* = the set whose contents (step s) are already in LDS,
     // ST* = the set holding step s+1
 #define CF_STEP(s_, cur_, LD0, LD1, LD2, LD3, ST0, ST1, ST2, ST3)                                   \
@@ -219,6 +288,7 @@ __global__ __launch_bounds__(64 * NWV, NWV / 2) void conv_fused_kernel(ConvFArgs
     for (int s = 0; s < nsteps; s += 2) {
         CF_STEP(s, 0, wa0, wa1, wa2, wa3, wb0, wb1, wb2, wb3);
         if (s + 1 < nsteps) CF_STEP(s + 1, 1, wb0, wb1, wb2, wb3, wa0, wa1, wa2, wa3);
+    }
     }
 #undef CF_STEP
 #undef CF_GLOAD_HALO
@@ -297,17 +367,20 @@ __global__ __launch_bounds__(64 * NWV, NWV / 2) void conv_fused_kernel(ConvFArgs
     }
 }
 
-template <int JN, int WNW, int KS, int NWV>
+template <int JN, int WNW, int KS, int NWV, bool DMA = false>
 static int launch_cf(const ConvFArgs& a, int B, hipStream_t st) {
     constexpr int PAD = KS / 2, NP = (8 + 2 * PAD) * (16 + 2 * PAD), NPP = (NP + 15) / 16 * 16;
     constexpr int BN = WNW * JN * 16;
     constexpr size_t lds = 2 * 4 * NPP * 16 + 2 * 2 * (BN / 16) * 1024;
     if (a.Npad % BN) return LGEN_ERR_BAD_ARG;
     dim3 grid(a.ntiles, a.Npad / BN, B);
-    hipLaunchKernelGGL((conv_fused_kernel<JN, WNW, KS, NWV>), grid, dim3(64 * NWV), lds, st, a);
+    hipLaunchKernelGGL((conv_fused_kernel<JN, WNW, KS, NWV, DMA>), grid, dim3(64 * NWV), lds, st, a);
     LGEN_CHECK_LAUNCH();
     return 0;
 }
+
+static int g_cf_dma = 1;  // weight tiles by LDS-DMA (1) or through staging registers (0); lgen_set_conv_fused_variant
+extern "C" int lgen_set_conv_fused_variant(int v) { g_cf_dma = v ? 1 : 0; return 0; }
 
 // weight tile width (output channels per workgroup) this library uses for a given Cout: the host packs to it
 extern "C" int lgen_conv_fused_bn(int Cout) { return Cout >= 128 ? 128 : (Cout > 16 ? 64 : 16); }
@@ -326,7 +399,10 @@ extern "C" int lgen_conv_fused(const float* x_nhwc, const float* gn_coef, int sw
     hipStream_t st = (hipStream_t)stream;
     // 4 waves x (64 ch x 64 px).  Measured alternative: 8 waves x (32 ch x 64 px) per workgroup (4 waves per SIMD instead of 2)
     // runs at the same speed (2.54 vs 2.57 ms, 16 x 384 px, 128 -> 128): the kernel is not short of waves to hide latency.
-    if (bn == 128) return ksize == 3 ? launch_cf<4, 2, 3, 4>(a, B, st) : launch_cf<4, 2, 1, 4>(a, B, st);
+    if (bn == 128) {
+        if (g_cf_dma) return ksize == 3 ? launch_cf<4, 2, 3, 4, true>(a, B, st) : launch_cf<4, 2, 1, 4, true>(a, B, st);
+        return ksize == 3 ? launch_cf<4, 2, 3, 4>(a, B, st) : launch_cf<4, 2, 1, 4>(a, B, st);
+    }
     if (bn == 64) return ksize == 3 ? launch_cf<4, 1, 3, 4>(a, B, st) : launch_cf<4, 1, 1, 4>(a, B, st);
     return ksize == 3 ? launch_cf<1, 1, 3, 4>(a, B, st) : launch_cf<1, 1, 1, 4>(a, B, st);
 }

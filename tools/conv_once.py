@@ -10,11 +10,14 @@ variant = int(a[5]) if len(a) > 5 else 0
 abl = int(a[6]) if len(a) > 6 else 0  # 1: no GroupNorm/swish, 2: no residual, 4: no statistics partials
 dev = torch.device("cuda:0")
 lib = L.lib()
+lib.lgen_set_conv_fused_variant(variant)
 torch.manual_seed(0)
 class Cv: pass
 cv = Cv(); cv.weight = (torch.randn(Cout, Cin, 3, 3) / (Cin * 9) ** 0.5).to(dev); cv.bias = torch.zeros(Cout, device=dev)
 cw = _ConvW(cv)
 x = torch.randn(B, H, H, Cin, device=dev)
+if abl & 8:  # zero operands: the DVFS / power check of the MI355X guide
+    x.zero_(); cw.frag.zero_()
 res = torch.randn(B, H, H, Cout, device=dev)
 coef = torch.stack([torch.ones(B, Cin, device=dev), torch.zeros(B, Cin, device=dev)], -1).contiguous()
 out = torch.empty(B, H, H, Cout, device=dev)

@@ -37,6 +37,7 @@ SIGNATURES = {
     "lgen_prefetch_hint": [_P, _c.c_longlong],
     "lgen_set_attn_variant": [_I],
     "lgen_set_igemm_variant": [_I],
+    "lgen_set_prefill_mfma": [_I],
     "lgen_set_conv_fused_variant": [_I],
     "lgen_stream_create_cu_mask": [_P, _I, _P],
     "lgen_stream_destroy": [_P],

@@ -654,6 +654,137 @@ __global__ __launch_bounds__(256) void attn_prefill_tiled_kernel(const void* __r
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// MFMA form of the prefill attention (bf16 storage): QK^T and PV on v_mfma_f32_16x16x32_bf16, flash-style.
+// One workgroup = (b, h, 64 queries); wave w owns 16 of them.  Per 32-key step:
+//   S^T[key][q] = K . Q^T      A = K rows straight from the cache (16 B per lane), B = Q (registers), fp32 accumulate;
+//                              the two operand roundings of ATen's math path ((q*sf).(k*sf)) become one fp32 scale by sf^2
+//   online softmax per query   a lane holds 4 keys x 2 tiles of one query column; max / sum across the 4 lane groups
+//   O^T[d][q] += V^T . P       A = V^T from an LDS tile written transposed ([d][key-slot], the only layout an MFMA can
+//                              contract over keys with), B = P as (hi, lo) bf16 -- two MFMA passes keep the fp32 softmax
+//                              weights to 2^-17, so the output carries one bf16 rounding like math-SDPA's (gpt.py:232-236)
+// Causal + optional per-row key mask exactly like the VALU kernels below.  fp32 storage keeps those kernels.
+// ---------------------------------------------------------------------------------------------
+template <int HDP>
+__global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const uint16_t* __restrict__ qrows, const uint16_t* __restrict__ kc,
+                                                                const uint16_t* __restrict__ vc, void* __restrict__ out,
+                                                                const unsigned char* __restrict__ mask, int T, int B2, int MTs,
+                                                                int H, int hd, int S8, int kvs, float scale) {
+    constexpr int KCH = HDP / 32, DT = HDP / 16, VLD = 40;  // V^T rows: 32 key slots + 8 pad (bank spread), bf16
+    __shared__ __attribute__((aligned(16))) uint16_t vt[HDP * VLD];
+    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    const int q0 = blockIdx.y * 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, r = lane & 15;
+    const int tq = q0 + wv * 16 + r;                 // this lane's query (column r of the wave's tiles)
+    const bool qok = tq < T;
+    const size_t kvbase = ((size_t)b * H + h) * S8;
+    // Q as the MFMA B operand: lane (g, r) holds query r, k-slice g*8.. of every 32-wide chunk
+    uint4 qf[KCH];
+#pragma unroll
+    for (int c = 0; c < KCH; ++c)
+        qf[c] = qok ? *(const uint4*)(qrows + ((size_t)((size_t)tq * B2 + b) * H + h) * HDP + c * 32 + g * 8) : make_uint4(0, 0, 0, 0);
+    const unsigned char* mrow = (mask && qok) ? mask + ((size_t)b * S8 + tq) * S8 : nullptr;
+    f32x4_t o[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d) o[d] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+    const int kend = min(T, q0 + 64);                // causal: no key beyond the tile's last query
+    const int wmax = q0 + wv * 16 + 15;              // last query of this wave
+    for (int k0 = 0; k0 < kend; k0 += 32) {
+        __syncthreads();                             // everybody is done with the previous V^T tile
+        // stage V^T: thread -> (key = tid / (HDP/8), 8 consecutive d); key slot e = (key & 3) + 4 * ((key >> 4) & 1) within lane
+        // group gq = (key >> 2) & 3, i.e. LDS column gq * 8 + e -- the order in which the P fragment holds its keys
+        for (int it = tid; it < 32 * (HDP / 8); it += 256) {
+            const int key = it / (HDP / 8), d8 = it - key * (HDP / 8);
+            const int kk = k0 + key;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (kk < kend) v = *(const uint4*)(vc + (kvbase + kk) * kvs + d8 * 8);
+            const int col = ((key >> 2) & 3) * 8 + (key & 3) + 4 * (key >> 4);
+            const uint16_t* pv = (const uint16_t*)&v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) vt[(d8 * 8 + e) * VLD + col] = pv[e];
+        }
+        __syncthreads();
+        if (k0 > wmax) continue;                     // the whole key tile lies in this wave's future (wave-uniform)
+        // S^T for two 16-key tiles
+        f32x4_t s2[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            int krow = k0 + kt * 16 + r;
+            krow = krow < S8 ? krow : S8 - 1;        // clamp (masked below); slots < S8 are always valid memory
+#pragma unroll
+            for (int c = 0; c < KCH; ++c) {
+                const uint4 kf = *(const uint4*)(kc + (kvbase + krow) * kvs + c * 32 + g * 8);
+                acc = BF16::mma(kf, qf[c], acc);
+            }
+            s2[kt] = acc;
+        }
+        // scale + mask; lane holds keys k0 + kt*16 + g*4 + j of query tq
+        float sv[8];
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int key = k0 + kt * 16 + g * 4 + j;
+                bool vis = qok && key <= tq && key < T;
+                if (vis && mrow) vis = mrow[key] != 0;
+                const float x = vis ? s2[kt][j] * scale : -INFINITY;
+                sv[kt * 4 + j] = x;
+                tmax = fmaxf(tmax, x);
+            }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = (m_run > -INFINITY) ? __expf(m_run - m_new) : 0.f;   // m_new = -inf only if nothing visible yet
+        float p[8], psum = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            p[e] = sv[e] > -INFINITY ? __expf(sv[e] - m_new) : 0.f;
+            psum += p[e];
+        }
+        psum += __shfl_xor(psum, 16, 64);
+        psum += __shfl_xor(psum, 32, 64);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+        // P as (hi, lo) bf16 B operands: lane (g, r) = query r, key slots g*8 + e in the order p[] holds them
+        uint4 ph = BF16::pack(p);
+        float ph_f[8], pl_f[8];
+        BF16::unpack(ph, ph_f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pl_f[e] = p[e] - ph_f[e];
+        const uint4 pl = BF16::pack(pl_f);
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+            const uint4 vf = *(const uint4*)(vt + (d * 16 + r) * VLD + g * 8);   // V^T rows d*16 + r, key slots g*8..
+            f32x4_t od = o[d];
+            od[0] *= alpha; od[1] *= alpha; od[2] *= alpha; od[3] *= alpha;
+            od = BF16::mma(vf, pl, od);
+            od = BF16::mma(vf, ph, od);
+            o[d] = od;
+        }
+    }
+    if (!qok) return;
+    const float inv = 1.0f / l_run;
+    const int rg = tq * B2 + b;                       // global row of this query in the packed activations
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+        const int dd = d * 16 + g * 4;               // lane holds output features dd .. dd+3 of query tq
+        if (dd + 3 < hd)
+            BF16::st4(out, BF16::xp_off(h * hd + dd, rg >> 4, rg & 15, MTs), o[d][0] * inv, o[d][1] * inv, o[d][2] * inv, o[d][3] * inv);
+        else
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (dd + j < hd) BF16::st(out, BF16::xp_off(h * hd + dd + j, rg >> 4, rg & 15, MTs), o[d][j] * inv);
+    }
+}
+
+static int g_prefill_mfma = 1;
+extern "C" int lgen_set_prefill_mfma(int v) { g_prefill_mfma = v ? 1 : 0; return 0; }
+
 template <typename D>
 static int launch_attn_prefill_tiled(const void* q_rows, const void* k_cache, const void* v_cache, void* out_packed,
                                      const unsigned char* mask, int T, int B2, int MTs, int n_head, int hd, int hdp, int S8, int kvs,
@@ -679,6 +810,17 @@ extern "C" int lgen_attn_prefill(const void* q_rows, const void* k_cache, const 
     if (T < 1 || T > S8 || (long long)B2 * T > (long long)MTs * 16) return LGEN_ERR_BAD_ARG;
     const int kvs = kv_row_stride > 0 ? kv_row_stride : hdp;
     const float sf = sqrtf(1.0f / sqrtf((float)hd));
+    if (dtype == LGEN_BF16 && g_prefill_mfma && (hdp == 64 || hdp == 128) && kvs % 8 == 0 && (hd & 3) == 0) {
+        dim3 grid(B2 * n_head, (T + 63) / 64);
+        if (hdp == 64)
+            hipLaunchKernelGGL(attn_prefill_mfma_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)q_rows,
+                               (const uint16_t*)k_cache, (const uint16_t*)v_cache, out_packed, mask, T, B2, MTs, n_head, hd, S8, kvs, sf * sf);
+        else
+            hipLaunchKernelGGL(attn_prefill_mfma_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)q_rows,
+                               (const uint16_t*)k_cache, (const uint16_t*)v_cache, out_packed, mask, T, B2, MTs, n_head, hd, S8, kvs, sf * sf);
+        LGEN_CHECK_LAUNCH();
+        return 0;
+    }
     if (T > PF_MAXT) {
         if (dtype == LGEN_BF16)
             return launch_attn_prefill_tiled<BF16>(q_rows, k_cache, v_cache, out_packed, mask, T, B2, MTs, n_head, hd, hdp, S8, kvs, sf,

@@ -549,11 +549,15 @@ def test_attn_prefill_any_length(dt, B2, H, hd, T, use_mask):
         pytest.skip("H * hd must be a multiple of the packing chunk")
     out = torch.zeros(d // kcd, mts, 64, kcd // 4, dtype=dt, device=dev)
     md = mask.to(dev).contiguous() if use_mask else None
-    L.check(L.lib().lgen_attn_prefill(L.ptr(q_d), L.ptr(kc_d), L.ptr(vc_d), L.ptr(out), L.ptr(md), T, B2, mts, H, hd, hdp, S8, 0,
-                                      code, L.stream()), "attn_prefill")
     ref = O.sdpa_math(q, k, v, mask[:, None, :T, :T], dt)                        # [B2, H, T, hd]
-    got = unpack_act(out, R).view(T, B2, H, hd).permute(1, 2, 0, 3)
-    _close(got, ref, dt, f"attn_prefill T={T} hd={hd} mask={use_mask}", frac_ulp1=0.05)
+    for mfma in ((1, 0) if dt == torch.bfloat16 else (1,)):  # bf16: the MFMA flash kernel (default) and the VALU kernels
+        L.lib().lgen_set_prefill_mfma(mfma)
+        out.zero_()
+        L.check(L.lib().lgen_attn_prefill(L.ptr(q_d), L.ptr(kc_d), L.ptr(vc_d), L.ptr(out), L.ptr(md), T, B2, mts, H, hd, hdp, S8, 0,
+                                          code, L.stream()), "attn_prefill")
+        got = unpack_act(out, R).view(T, B2, H, hd).permute(1, 2, 0, 3)
+        _close(got, ref, dt, f"attn_prefill T={T} hd={hd} mask={use_mask} mfma={mfma}", frac_ulp1=0.05)
+    L.lib().lgen_set_prefill_mfma(1)
 
 
 @pytest.mark.parametrize("dt", DTYPES)

@@ -6,7 +6,7 @@ autoregressive/sample/sample_c2i.py (:18-98 main, :101-123 flags), with the thre
     python examples/sample_c2i.py --vq-ckpt vq_ds16_c2i.pt --gpt-ckpt c2i_L_384.pt --gpt-model GPT-L --image-size 384
 
 Differences that are deliberate: `--compile` is accepted and ignored (the decode step is always one captured hipGraph),
-`--precision fp16` is refused by the engine (bf16 / none are built), the image grid is written with PIL (torchvision is
+all three `--precision` choices run on the HIP kernels (bf16, fp16, none = fp32), the image grid is written with PIL (torchvision is
 not a dependency) and `main()` returns the tensors so that a test can hold them against the oracle.
 """
 import argparse

@@ -29,6 +29,7 @@ extern "C" {
 #define LGEN_ABI_VERSION 4
 #define LGEN_BF16 0
 #define LGEN_F32 1
+#define LGEN_F16 2   /* fp16 storage: BF16's layouts (KC = 32, EPL = 8), IEEE half rounding, v_mfma_f32_16x16x32_f16 */
 
 #define LGEN_ERR_BAD_ARG (-1)
 #define LGEN_ERR_UNSUPPORTED (-2)

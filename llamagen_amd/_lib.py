@@ -15,7 +15,7 @@ import torch  # noqa: F401  (loads libamdhip64 first)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblgen_hip.so")
-BF16, F32 = 0, 1
+BF16, F32, F16 = 0, 1, 2
 EPI_ROWS, EPI_PACKED, EPI_GELU, EPI_RES, EPI_SWIGLU, EPI_QKV = 0, 1, 2, 3, 4, 5
 ABI_VERSION = 4
 ERR_UNSUPPORTED = -2

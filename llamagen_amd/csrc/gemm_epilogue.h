@@ -105,8 +105,7 @@ LGEN_DEV void epilogue(const GemmArgs& a, int nt, int mt, int lane, f32x4_t v, f
     } else if constexpr (EPI == EPI_RES) {
         float h0, h1, h2, h3;
         if constexpr (D::ESZ == 2) {
-            h0 = __uint_as_float(aux.x << 16); h1 = __uint_as_float(aux.x & 0xffff0000u);
-            h2 = __uint_as_float(aux.y << 16); h3 = __uint_as_float(aux.y & 0xffff0000u);
+            D::unpack4(make_uint2(aux.x, aux.y), h0, h1, h2, h3);
         } else {
             h0 = __uint_as_float(aux.x); h1 = __uint_as_float(aux.y);
             h2 = __uint_as_float(aux.z); h3 = __uint_as_float(aux.w);

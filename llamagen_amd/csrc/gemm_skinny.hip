@@ -242,6 +242,7 @@ template <int EPI, bool NORM>
 static int dispatch_dt(const GemmArgs& a, int dtype, int mt, int nt, int kw, hipStream_t st) {
     if (dtype == LGEN_BF16) return dispatch<BF16, EPI, NORM>(a, mt, nt, kw, st);
     if (dtype == LGEN_F32) return dispatch<F32, EPI, NORM>(a, mt, nt, kw, st);
+    if (dtype == LGEN_F16) return dispatch<F16, EPI, NORM>(a, mt, nt, kw, st);
     return LGEN_ERR_BAD_ARG;
 }
 
@@ -296,7 +297,7 @@ extern "C" int lgen_gemm_max_kw(int epilogue_kind, int fused_norm, int mt, int n
 extern "C" int lgen_gemm(const void* wp, const void* xp, void* out, int M, int MTs, int N, int K, int epilogue_kind,
                          int dtype, int mt, int nt, int kw, const void* norm_w, const float* ssq_in, int ssq_parts,
                          float eps, float* ssq_out, void* stream) {
-    const int kcsz = dtype == LGEN_BF16 ? 32 : 16;
+    const int kcsz = dtype != LGEN_F32 ? 32 : 16;
     if (N % 16 || K % kcsz || M > MTs * 16) return LGEN_ERR_BAD_ARG;
     GemmArgs a{};
     a.wp = (const uint4*)wp; a.xp = (const uint4*)xp; a.out = out;
@@ -321,7 +322,7 @@ static int qkv_rope_impl(const void* wp, const void* xp, void* q_out, void* k_ca
                          const int* pos_ptr, int pos_stride, int M, int MTs, int d, int n_head, int hd, int hdp, int S8,
                          int kv_row_stride, int dtype, int mt, int nt, int kw, const void* norm_w, const float* ssq_in,
                          int ssq_parts, float eps, void* stream) {
-    const int kcsz = dtype == LGEN_BF16 ? 32 : 16;
+    const int kcsz = dtype != LGEN_F32 ? 32 : 16;
     if (d % kcsz || (3 * d) % 16 || hd % 4 || d != n_head * hd || M > MTs * 16 || pos_stride < 0 || pos_stride > 1)
         return LGEN_ERR_BAD_ARG;
     GemmArgs a{};

@@ -63,6 +63,10 @@ extern "C" int lgen_embed_pack(const void* table, const int* idx, void* hp, floa
         int total = (d / 32) * MTs * 64;
         hipLaunchKernelGGL(embed_pack_kernel<BF16>, dim3((total + 255) / 256), dim3(256), 0, st, (const uint4*)table, idx,
                            (uint4*)hp, ssq_out, state_advance, M, MTs, d, rows);
+    } else if (dtype == LGEN_F16) {
+        int total = (d / 32) * MTs * 64;
+        hipLaunchKernelGGL(embed_pack_kernel<F16>, dim3((total + 255) / 256), dim3(256), 0, st, (const uint4*)table, idx,
+                           (uint4*)hp, ssq_out, state_advance, M, MTs, d, rows);
     } else if (dtype == LGEN_F32) {
         int total = (d / 16) * MTs * 64;
         hipLaunchKernelGGL(embed_pack_kernel<F32>, dim3((total + 255) / 256), dim3(256), 0, st, (const uint4*)table, idx,
@@ -85,6 +89,10 @@ extern "C" int lgen_embed_rows(const void* tok_table, const void* cls_table, con
     if (dtype == LGEN_BF16) {
         int total = (d / 32) * MTs * 64;
         hipLaunchKernelGGL(embed_pack_kernel<BF16>, dim3((total + 255) / 256), dim3(256), 0, st, (const uint4*)tok_table, cur_tok,
+                           (uint4*)hp, ssq_out, (int*)nullptr, M, MTs, d, tok_rows, (const uint4*)cls_table, cond, row_pos, cls_rows);
+    } else if (dtype == LGEN_F16) {
+        int total = (d / 32) * MTs * 64;
+        hipLaunchKernelGGL(embed_pack_kernel<F16>, dim3((total + 255) / 256), dim3(256), 0, st, (const uint4*)tok_table, cur_tok,
                            (uint4*)hp, ssq_out, (int*)nullptr, M, MTs, d, tok_rows, (const uint4*)cls_table, cond, row_pos, cls_rows);
     } else if (dtype == LGEN_F32) {
         int total = (d / 16) * MTs * 64;
@@ -123,6 +131,9 @@ extern "C" int lgen_ssq_pack(const void* hp, float* ssq_out, int MTs, int d, int
     if (dtype == LGEN_BF16) {
         int total = (d / 32) * MTs * 64;
         hipLaunchKernelGGL(ssq_pack_kernel<BF16>, dim3((total + 255) / 256), dim3(256), 0, st, (const uint4*)hp, ssq_out, total, MTs);
+    } else if (dtype == LGEN_F16) {
+        int total = (d / 32) * MTs * 64;
+        hipLaunchKernelGGL(ssq_pack_kernel<F16>, dim3((total + 255) / 256), dim3(256), 0, st, (const uint4*)hp, ssq_out, total, MTs);
     } else if (dtype == LGEN_F32) {
         int total = (d / 16) * MTs * 64;
         hipLaunchKernelGGL(ssq_pack_kernel<F32>, dim3((total + 255) / 256), dim3(256), 0, st, (const uint4*)hp, ssq_out, total, MTs);
@@ -195,7 +206,7 @@ __global__ __launch_bounds__(1024) void rmsnorm_kernel(const uint4* __restrict__
 extern "C" int lgen_rmsnorm(const void* hp, const void* weight, void* xnp, int MTs, int d, float eps, int dtype,
                             void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    const int kcsz = dtype == LGEN_BF16 ? 32 : 16;
+    const int kcsz = dtype != LGEN_F32 ? 32 : 16;
     if (d % kcsz) return LGEN_ERR_BAD_ARG;
     const int KCH = d / kcsz;
     int nw = 4;
@@ -205,6 +216,7 @@ extern "C" int lgen_rmsnorm(const void* hp, const void* weight, void* xnp, int M
 #define LGEN_RMS(DT, C) hipLaunchKernelGGL((rmsnorm_kernel<DT, C>), dim3(MTs), dim3(64 * nw), 0, st, (const uint4*)hp, weight, \
                                            (uint4*)xnp, MTs, d, eps)
     if (dtype == LGEN_BF16) { if (wide) LGEN_RMS(BF16, 16); else LGEN_RMS(BF16, 8); }
+    else if (dtype == LGEN_F16) { if (wide) LGEN_RMS(F16, 16); else LGEN_RMS(F16, 8); }
     else if (dtype == LGEN_F32) { if (wide) LGEN_RMS(F32, 16); else LGEN_RMS(F32, 8); }
     else return LGEN_ERR_BAD_ARG;
 #undef LGEN_RMS
@@ -376,8 +388,8 @@ static int attn_decode_impl(const void* q, const void* k_cache, const void* v_ca
     lgen_take_prefetch_hint(&a.pf, &a.pf_bytes);
     a.sf = sqrtf(1.0f / sqrtf((float)hd));
     hipStream_t st = (hipStream_t)stream;
-    const int epl = dtype == LGEN_BF16 ? 8 : 4;
-    if (dtype != LGEN_BF16 && dtype != LGEN_F32) return LGEN_ERR_BAD_ARG;
+    const int epl = dtype != LGEN_F32 ? 8 : 4;
+    if (dtype != LGEN_BF16 && dtype != LGEN_F32 && dtype != LGEN_F16) return LGEN_ERR_BAD_ARG;
     if (hdp % epl || hd > hdp || B2 > MTs * 16 || S8 < 1 || a.kvs < hdp || a.kvs % epl) return LGEN_ERR_BAD_ARG;
     const int lpk = hdp / epl;
     const int nw = g_attn_variant >= 4 ? 1 : (g_attn_variant >= 2 ? 2 : 4);
@@ -393,6 +405,8 @@ static int attn_decode_impl(const void* q, const void* k_cache, const void* v_ca
     } while (0)
     if (dtype == LGEN_BF16 && lpk == 8) LGEN_ATT(BF16, 8);
     else if (dtype == LGEN_BF16 && lpk == 16) LGEN_ATT(BF16, 16);
+    else if (dtype == LGEN_F16 && lpk == 8) LGEN_ATT(F16, 8);
+    else if (dtype == LGEN_F16 && lpk == 16) LGEN_ATT(F16, 16);
     else if (dtype == LGEN_F32 && lpk == 16) LGEN_ATT(F32, 16);
     else if (dtype == LGEN_F32 && lpk == 32) LGEN_ATT(F32, 32);
     else return LGEN_ERR_BAD_ARG;
@@ -471,7 +485,7 @@ __global__ __launch_bounds__(256) void rope_append_prefill_kernel(const uint4* _
 extern "C" int lgen_rope_append_prefill(const void* qkv_packed, void* q_rows, void* k_cache, void* v_cache, const float* freqs,
                                         int R, int B2, int MTs, int d, int n_head, int hd, int hdp, int S8, int kv_row_stride,
                                         int pos0, int dtype, void* stream) {
-    const int kcsz = dtype == LGEN_BF16 ? 32 : 16;
+    const int kcsz = dtype != LGEN_F32 ? 32 : 16;
     if ((3 * d) % kcsz || d != n_head * hd || hd % 2 || R > MTs * 16 || B2 < 1 || R % B2) return LGEN_ERR_BAD_ARG;
     const int kvs = kv_row_stride > 0 ? kv_row_stride : hdp;
     const long long total = (long long)(3 * d / kcsz) * MTs * 64;
@@ -479,6 +493,9 @@ extern "C" int lgen_rope_append_prefill(const void* qkv_packed, void* q_rows, vo
     hipStream_t st = (hipStream_t)stream;
     if (dtype == LGEN_BF16)
         hipLaunchKernelGGL(rope_append_prefill_kernel<BF16>, dim3(blocks), dim3(256), 0, st, (const uint4*)qkv_packed, q_rows, k_cache,
+                           v_cache, freqs, R, B2, MTs, d, n_head, hd, hdp, S8, kvs, pos0);
+    else if (dtype == LGEN_F16)
+        hipLaunchKernelGGL(rope_append_prefill_kernel<F16>, dim3(blocks), dim3(256), 0, st, (const uint4*)qkv_packed, q_rows, k_cache,
                            v_cache, freqs, R, B2, MTs, d, n_head, hd, hdp, S8, kvs, pos0);
     else if (dtype == LGEN_F32)
         hipLaunchKernelGGL(rope_append_prefill_kernel<F32>, dim3(blocks), dim3(256), 0, st, (const uint4*)qkv_packed, q_rows, k_cache,
@@ -828,6 +845,9 @@ extern "C" int lgen_attn_prefill(const void* q_rows, const void* k_cache, const 
         if (dtype == LGEN_F32)
             return launch_attn_prefill_tiled<F32>(q_rows, k_cache, v_cache, out_packed, mask, T, B2, MTs, n_head, hd, hdp, S8, kvs, sf,
                                                   (hipStream_t)stream);
+        if (dtype == LGEN_F16)
+            return launch_attn_prefill_tiled<F16>(q_rows, k_cache, v_cache, out_packed, mask, T, B2, MTs, n_head, hd, hdp, S8, kvs, sf,
+                                                  (hipStream_t)stream);
         return LGEN_ERR_BAD_ARG;
     }
     const size_t lds = ((size_t)2 * T * (hd + 1) + 4 * PF_MAXT + 4 * hd) * sizeof(float);
@@ -839,6 +859,13 @@ extern "C" int lgen_attn_prefill(const void* q_rows, const void* k_cache, const 
             if (e != hipSuccess) return (int)e;
         }
         hipLaunchKernelGGL(attn_prefill_kernel<BF16>, dim3(B2 * n_head), dim3(256), lds, st, q_rows, k_cache, v_cache, out_packed, mask,
+                           T, B2, MTs, n_head, hd, hdp, S8, kvs, sf);
+    } else if (dtype == LGEN_F16) {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void*)attn_prefill_kernel<F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+        }
+        hipLaunchKernelGGL(attn_prefill_kernel<F16>, dim3(B2 * n_head), dim3(256), lds, st, q_rows, k_cache, v_cache, out_packed, mask,
                            T, B2, MTs, n_head, hd, hdp, S8, kvs, sf);
     } else if (dtype == LGEN_F32) {
         if (lds > 64 * 1024) {

@@ -69,6 +69,10 @@ struct BF16 {
         a = __uint_as_float(u.x << 16); b = __uint_as_float(u.x & 0xffff0000u);
         c = __uint_as_float(u.y << 16); d = __uint_as_float(u.y & 0xffff0000u);
     }
+    LGEN_DEV static void unpack4(const uint2& u, float& a, float& b, float& c, float& d) {
+        a = __uint_as_float(u.x << 16); b = __uint_as_float(u.x & 0xffff0000u);
+        c = __uint_as_float(u.y << 16); d = __uint_as_float(u.y & 0xffff0000u);
+    }
     LGEN_DEV static void ld8(const void* p, size_t i, float (&f)[8]) {  // 8 consecutive elements, 16-byte aligned
         unpack(*(const uint4*)((const uint16_t*)p + i), f);
     }
@@ -140,6 +144,67 @@ struct F32 {
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
         return c;
+    }
+};
+
+
+// fp16 storage (the reference's --precision fp16, sample_c2i.py:108): same layouts as BF16 (2-byte elements, KC = 32, EPL = 8),
+// IEEE half rounding points, v_mfma_f32_16x16x32_f16 with fp32 accumulation.
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
+typedef __attribute__((ext_vector_type(8))) float f32x8_t;
+struct F16 {
+    static constexpr int EPL = 8;
+    static constexpr int KC = 32;
+    static constexpr int ESZ = 2;
+    static constexpr int CODE = 2;
+    typedef uint16_t elem_t;
+    LGEN_DEV static float h2f(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+    LGEN_DEV static uint16_t f2h(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+    LGEN_DEV static float rnd(float f) { return h2f(f2h(f)); }
+    LGEN_DEV static float fexp(float x) { return __expf(x); }
+    LGEN_DEV static float ld(const void* p, size_t i) { return h2f(((const uint16_t*)p)[i]); }
+    LGEN_DEV static void st(void* p, size_t i, float v) { ((uint16_t*)p)[i] = f2h(v); }
+    LGEN_DEV static void unpack(const uint4& u, float (&f)[8]) {
+        const f32x8_t v = __builtin_convertvector(__builtin_bit_cast(f16x8_t, u), f32x8_t);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = v[e];
+    }
+    LGEN_DEV static uint4 pack(const float (&f)[8]) {
+        f32x8_t v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = f[e];
+        return __builtin_bit_cast(uint4, __builtin_convertvector(v, f16x8_t));
+    }
+    LGEN_DEV static void st4(void* p, size_t i, float a, float b, float c, float d) {
+        const f32x4_t v = {a, b, c, d};
+        *(uint2*)((uint16_t*)p + i) = __builtin_bit_cast(uint2, __builtin_convertvector(v, f16x4_t));
+    }
+    LGEN_DEV static void ld4(const void* p, size_t i, float& a, float& b, float& c, float& d) {
+        const uint2 u = *(const uint2*)((const uint16_t*)p + i);
+        const f32x4_t v = __builtin_convertvector(__builtin_bit_cast(f16x4_t, u), f32x4_t);
+        a = v[0]; b = v[1]; c = v[2]; d = v[3];
+    }
+    LGEN_DEV static void unpack4(const uint2& u, float& a, float& b, float& c, float& d) {
+        const f32x4_t v = __builtin_convertvector(__builtin_bit_cast(f16x4_t, u), f32x4_t);
+        a = v[0]; b = v[1]; c = v[2]; d = v[3];
+    }
+    LGEN_DEV static void ld8(const void* p, size_t i, float (&f)[8]) { unpack(*(const uint4*)((const uint16_t*)p + i), f); }
+    LGEN_DEV static size_t xp_off(int k, int mt, int r, int MTs) { return BF16::xp_off(k, mt, r, MTs); }
+    LGEN_DEV static uint4 norm_chunk(const uint4& x, float ri, const uint4& w) {
+        float f[8], wf[8];
+        unpack(x, f);
+        unpack(w, wf);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = f[e] * ri;
+        const uint4 t = pack(f);
+        unpack(t, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = f[e] * wf[e];
+        return pack(f);
+    }
+    LGEN_DEV static f32x4_t mma(const uint4& a, const uint4& b, f32x4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
     }
 };
 

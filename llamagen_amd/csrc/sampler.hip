@@ -453,6 +453,9 @@ static int sample_impl(const void* logits, const float* noise, long long noise_s
                                             SMP_MAXV * (int)sizeof(float));
         hipError_t e2 = hipFuncSetAttribute((const void*)sample_kernel<F32>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             SMP_MAXV * (int)sizeof(float));
+        hipError_t e3 = hipFuncSetAttribute((const void*)sample_kernel<F16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            SMP_MAXV * (int)sizeof(float));
+        if (e3 != hipSuccess) return (int)e3;
         if (e1 != hipSuccess) return (int)e1;
         if (e2 != hipSuccess) return (int)e2;
         attr_set = true;
@@ -461,6 +464,8 @@ static int sample_impl(const void* logits, const float* noise, long long noise_s
         hipLaunchKernelGGL(sample_kernel<BF16>, dim3(B), dim3(SMP_THREADS), lds, st, a);
     else if (dtype == LGEN_F32)
         hipLaunchKernelGGL(sample_kernel<F32>, dim3(B), dim3(SMP_THREADS), lds, st, a);
+    else if (dtype == LGEN_F16)
+        hipLaunchKernelGGL(sample_kernel<F16>, dim3(B), dim3(SMP_THREADS), lds, st, a);
     else
         return LGEN_ERR_BAD_ARG;
     LGEN_CHECK_LAUNCH();

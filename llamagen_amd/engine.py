@@ -25,7 +25,7 @@ def _ceil_div(a, b):
 def pack_weight(w: torch.Tensor) -> torch.Tensor:
     """[N, K] row-major -> WP[N/16][K/KC][4 g][16 r][EPL] (one-time layout transform)."""
     N, K = w.shape
-    epl = 8 if w.dtype == torch.bfloat16 else 4
+    epl = 4 if w.dtype == torch.float32 else 8
     kc = 4 * epl
     assert N % 16 == 0 and K % kc == 0, (N, K)
     return w.view(N // 16, 16, K // kc, 4, epl).permute(0, 2, 3, 1, 4).contiguous()
@@ -34,7 +34,7 @@ def pack_weight(w: torch.Tensor) -> torch.Tensor:
 def pack_act(x: torch.Tensor, mts: int) -> torch.Tensor:
     """[M, K] row-major -> XP[K/KC][MTs][4 g][16 r][EPL] (rows padded with zeros)."""
     M, K = x.shape
-    epl = 8 if x.dtype == torch.bfloat16 else 4
+    epl = 4 if x.dtype == torch.float32 else 8
     kc = 4 * epl
     assert K % kc == 0 and M <= mts * 16
     xp = torch.zeros(mts * 16, K, dtype=x.dtype, device=x.device)
@@ -96,8 +96,8 @@ _PACKED = weakref.WeakKeyDictionary()  # tok_embeddings module (shared by lane v
 class DecodeEngine:
     def __init__(self, model, max_batch: int, S8: int, dtype: torch.dtype):
         cfg = model.config
-        if dtype not in (torch.bfloat16, torch.float32):
-            raise NotImplementedError("the HIP engine implements --precision bf16 and none (fp32); fp16 is not built")
+        if dtype not in (torch.bfloat16, torch.float32, torch.float16):
+            raise NotImplementedError(f"the HIP engine implements --precision bf16, fp16 and none (fp32), not {dtype}")
         self.lib = L.lib()
         if os.environ.get("LGEN_WEIGHT_NT") is not None:  # tuning knob, see lgen_set_weight_nt in lgen.h
             self.lib.lgen_set_weight_nt(int(os.environ["LGEN_WEIGHT_NT"]))
@@ -107,8 +107,8 @@ class DecodeEngine:
             self.lib.lgen_set_attn_variant(int(os.environ["LGEN_ATTN_VARIANT"]))
         self.dev = model.tok_embeddings.weight.device
         self.dtype = dtype
-        self.dt = L.BF16 if dtype == torch.bfloat16 else L.F32
-        self.epl = 8 if dtype == torch.bfloat16 else 4
+        self.dt = {torch.bfloat16: L.BF16, torch.float32: L.F32, torch.float16: L.F16}[dtype]
+        self.epl = 4 if dtype == torch.float32 else 8
         self.kc = 4 * self.epl
         self.B2, self.S8 = max_batch, S8
         self.L, self.H, self.d = cfg.n_layer, cfg.n_head, cfg.dim

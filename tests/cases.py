@@ -33,6 +33,8 @@ GPT_CASES = {
     # bf16: reference tokens are stored and used for TEACHER FORCING; logits compared to tolerance
     "tiny_bf16": _c(_TINY, dtype="bf16", trace_steps=list(range(16))),
     "hd100_bf16": _c(_HD100, dtype="bf16", batch=2, top_k=300, trace_steps=list(range(16))),
+    # --precision fp16 (sample_c2i.py:108): same teacher-forced comparison in IEEE half
+    "tiny_fp16": _c(_TINY, dtype="fp16", trace_steps=list(range(16))),
     # BASELINE.json configs[0]: LlamaGen-B 256px, single image, cfg 1.0, fp32, top-k 2000
     "gptb_c1": _c(_GPTB, registry="GPT-B", batch=1, n_new=256, cfg_scale=1.0, top_k=2000, lin_std=0.02,
                   trace_steps=[0, 1, 128, 255]),

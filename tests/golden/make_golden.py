@@ -42,7 +42,7 @@ def build_ref_gpt(case):
     sd = synth_for_module(m, seed=case["wseed"], lin_std=case.get("lin_std", 0.02))
     missing = m.load_state_dict(sd, strict=False)
     assert not missing.unexpected_keys, missing
-    dt = {"fp32": torch.float32, "bf16": torch.bfloat16}[case["dtype"]]
+    dt = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[case["dtype"]]
     return m.to(dtype=dt).eval()
 
 

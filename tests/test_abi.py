@@ -157,9 +157,9 @@ def test_hot_kernels_have_no_register_spills():
             if m and cur is not None:
                 cur[m.group(1).strip()] = int(m.group(2))
     assert len(kernels) > 100
-    allowed = [r"gemm_kernelI4BF16Li8ELi2ELi\dELb1ELi2E",      # ring-buffer NORM GEMM at mt = 8 (engine uses mt <= 4)
-               r"gemm_kernelI4BF16Li4ELi4ELi5ELb1ELi2E",         # ring-buffer NORM qkv at (4, 4): fused qkv runs (1, 4) / (2, 4)
-               r"rmsnorm_kernelI4BF16Li16E",                     # bf16 rows wider than 4096 (no registry model)
+    allowed = [r"gemm_kernelI(4BF16|3F16)Li8ELi2ELi\dELb1ELi2E",  # ring-buffer NORM GEMM at mt = 8 (engine uses mt <= 4)
+               r"gemm_kernelI(4BF16|3F16)Li4ELi4ELi5ELb1ELi2E",     # ring-buffer NORM qkv at (4, 4): fused qkv runs (1, 4) / (2, 4)
+               r"rmsnorm_kernelI(4BF16|3F16)Li16E",                 # 16-bit rows wider than 4096 (no registry model)
                r"igemm_kernelILi4ELi4ELi2ELi1E"]                 # conv variant 1 (double-staged both operands), not the default
     spilled = [n for n, r in kernels.items() if r.get("ScratchSize", 0) > 0 or r.get("VGPRs Spill", 0) > 0]
     unexpected = [n for n in spilled if not any(re.search(a, n) for a in allowed)]

@@ -9,7 +9,8 @@ from tests.cases import GPT_CASES, VQ_CASES, make_gpt_inputs, make_vq_inputs, no
 from tests.util import DT, build_gpt_holder, build_vq_holder, load_golden, oracle_cfg
 
 FP32_CASES = [k for k, c in GPT_CASES.items() if c["dtype"] == "fp32"]
-BF16_CASES = [k for k, c in GPT_CASES.items() if c["dtype"] == "bf16"]
+BF16_CASES = [k for k, c in GPT_CASES.items() if c["dtype"] in ("bf16", "fp16")]
+ULP = {"bf16": 2.0 ** -8, "fp16": 2.0 ** -11}  # storage resolution relative to the largest logit
 
 
 def _run_oracle(case, teacher=None):
@@ -48,10 +49,12 @@ def test_oracle_logits_teacher_forced_bf16(name):
     ref = gold["trace_logits"]
     got = np.stack([trace[int(s)].numpy() for s in gold["trace_steps"]])
     scale = np.abs(ref).max()
-    ulp = scale * 2.0 ** -8
+    ulp = scale * ULP[case["dtype"]]
     err = np.abs(got - ref)
     assert err.max() <= 4 * ulp, (err.max(), ulp)
-    assert err.mean() <= 0.25 * ulp, (err.mean(), ulp)
+    # fp16: torch-CPU's half GEMM is not a single-rounded fp32 accumulation (0.12 % of nn.Linear outputs differ from it,
+    # measured; 0 % in bf16), so the fp16 golden itself carries ~1 extra flip per logit: mean bar 0.5 ulp instead of 0.25
+    assert err.mean() <= (0.5 if case["dtype"] == "fp16" else 0.25) * ulp, (err.mean(), ulp)
     agree = (toks.numpy() == gold["tokens"]).mean()
     assert agree >= 0.8, agree  # sampler given near-identical logits and the same noise
 

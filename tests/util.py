@@ -10,7 +10,7 @@ from llamagen_amd.vq_model import VQ_models
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-DT = {"fp32": torch.float32, "bf16": torch.bfloat16}
+DT = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}
 
 
 def load_golden(name):

@@ -129,6 +129,7 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(SampleArgs a) {
     __shared__ unsigned long long hm[SMP_NB];       // top-p: probability mass per value bin, 2^-40 fixed point
     __shared__ unsigned long long wtot64[SMP_THREADS / 64], sh_gab;
     __shared__ unsigned sh_key;
+    __shared__ unsigned tie_w[SMP_NS][SMP_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int b = blockIdx.x, V = a.V, B = a.B;
     const int step = a.row_step ? a.row_step[b] : a.state[1];
@@ -301,8 +302,8 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(SampleArgs a) {
     float tot = sh_f;
 
     // 3b. nucleus (top-p) filter on the top-k survivors (generate.py:38-53): an entry stays iff the probability
-    // mass of the strictly larger entries is <= top_p (the reference's shifted `cumsum > top_p` removal; entries
-    // of equal value share their fate here, where the reference's unstable sort picks arbitrarily).  Masses are
+    // mass of the strictly larger entries is <= top_p (the reference's shifted `cumsum > top_p` removal); of the entries
+    // equal to that threshold value the lowest-index ones stay, as many as the reference's sort order keeps.  Masses are
     // 2^-40 fixed point, so every sum is order-independent: value-bin mass histogram -> critical bin by suffix
     // scan -> exact mass ranking inside that bin.
     if (a.top_p < 1.0f) {
@@ -370,15 +371,63 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(SampleArgs a) {
                 __syncthreads();
                 const uint32_t key = sh_key;
                 const float thr_p = __uint_as_float((key & 0x80000000u) ? (key & 0x7fffffffu) : ~key);
+                // Ties AT the threshold value.  The reference sorts descending and its shifted `cumsum > top_p` removes the tail of a
+                // tie group in SORT order; torch's GPU sort is a stable radix sort (ties in ascending index -- the CPU sort of the same
+                // call is unstable and keeps an arbitrary subset of the same SIZE), so: of the c entries equal to thr_p keep the
+                // n_keep = floor((P - G) / m) + 1 lowest-index ones (G = mass strictly above thr_p, m = mass of one such entry).
+                unsigned long long gpart = 0ull;
+                unsigned cnt[SMP_NS];
+#pragma unroll
+                for (int s = 0; s < SMP_NS; ++s) {
+                    cnt[s] = 0;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (ex[s][e] > 0.f) {
+                            if (l[s][e] > thr_p) gpart += mass(ex[s][e]);
+                            else if (l[s][e] == thr_p) cnt[s] += 1;
+                        }
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) gpart += __shfl_xor(gpart, o, 64);
+                unsigned incl_c[SMP_NS];  // inclusive scan of the tie counts over the lanes of this wave (index order = (s, thread, e))
+#pragma unroll
+                for (int s = 0; s < SMP_NS; ++s) {
+                    unsigned v = cnt[s];
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const unsigned u = __shfl_up(v, o, 64);
+                        if (lane >= o) v += u;
+                    }
+                    incl_c[s] = v;
+                }
+                __syncthreads();
+                if (lane == 63) { tie_w[0][wv] = incl_c[0]; tie_w[1][wv] = incl_c[1]; }
+                if (lane == 0) wtot64[wv] = gpart;
+                __syncthreads();
+                unsigned long long G = 0ull;
+                unsigned before[SMP_NS], total_c = 0, tot0 = 0;
+                for (int i = 0; i < SMP_THREADS / 64; ++i) { G += wtot64[i]; tot0 += tie_w[0][i]; total_c += tie_w[0][i] + tie_w[1][i]; }
+                before[0] = incl_c[0] - cnt[0];
+                before[1] = tot0 + incl_c[1] - cnt[1];
+                for (int i = 0; i < wv; ++i) { before[0] += tie_w[0][i]; before[1] += tie_w[1][i]; }
+                const unsigned long long m1 = mass(expf(thr_p - rmax));
+                unsigned long long nk = m1 > 0ull ? (P >= G ? (P - G) / m1 + 1ull : 1ull) : (unsigned long long)total_c;
+                const unsigned n_keep = nk > (unsigned long long)total_c ? total_c : (unsigned)nk;
                 // re-normalise over the nucleus
                 lsum = 0.f;
 #pragma unroll
-                for (int s = 0; s < SMP_NS; ++s)
+                for (int s = 0; s < SMP_NS; ++s) {
+                    unsigned rank = before[s];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         if (!(l[s][e] >= thr_p)) ex[s][e] = 0.f;
+                        else if (ex[s][e] > 0.f && l[s][e] == thr_p) {
+                            if (rank >= n_keep) ex[s][e] = 0.f;
+                            rank += 1;
+                        }
                         lsum += ex[s][e];
                     }
+                }
                 lsum = wave_sum(lsum);
                 if (lane == 0) red_f[wv] = lsum;
                 __syncthreads();

@@ -251,7 +251,10 @@ def top_k_top_p_filtering(logits: Tensor, top_k: int = 0, top_p: float = 1.0) ->
         kth = torch.sort(logits, dim=-1, descending=True)[0][..., k - 1, None]
         logits[logits < kth] = -float("inf")
     if top_p < 1.0:
-        sl, si = torch.sort(logits, descending=True)
+        # stable: ties in ascending index order, which is what torch's GPU sort (a stable radix sort) gives the reference;
+        # the CPU sort of the same call is unstable and keeps an arbitrary subset of a tie group -- of the SAME size
+        # (tests/golden/topp_ties.npz pins the size against the reference itself)
+        sl, si = torch.sort(logits, descending=True, stable=True)
         cp = torch.cumsum(torch.softmax(sl, dim=-1), dim=-1)
         rem = cp > top_p
         rem[..., 1:] = rem[..., :-1].clone()

@@ -96,3 +96,20 @@ def noise_stream(rseed: int):
     def fn(shape):
         return torch.empty(tuple(shape), dtype=torch.float32).exponential_(1, generator=g)
     return fn
+
+
+def make_topp_tie_rows(V=16384, rows=6, seed=31):
+    """Adversarial top-p inputs: every row has one large tie group (40..400 equal logits at scattered indices) that the nucleus
+    boundary cuts through, plus a few larger entries and a low tail.  Returns (logits fp32 [rows, V], top_p list)."""
+    g = torch.Generator().manual_seed(seed)
+    l = torch.full((rows, V), -6.0) + 0.5 * torch.randn(rows, V, generator=g)
+    tops = []
+    for r in range(rows):
+        perm = torch.randperm(V, generator=g)
+        nbig, ntie = 1 + r, 40 * (1 + r % 3) * (1 + r // 3 * 4)
+        l[r, perm[:nbig]] = 3.0 + 0.25 * torch.arange(nbig, dtype=torch.float32)
+        l[r, perm[nbig:nbig + ntie]] = 1.0
+        p = torch.softmax(l[r], -1)
+        frac = (0.37, 0.5, 0.81, 0.12, 0.66, 0.95)[r % 6]
+        tops.append(float(p[perm[:nbig]].sum() + (frac * ntie) * p[perm[nbig]]))
+    return l, tops

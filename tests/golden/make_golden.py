@@ -101,8 +101,23 @@ def run_vq_case(name, case):
     np.savez_compressed(os.path.join(HERE, f"vq_{name}.npz"), **arrs)
 
 
+def run_topp_ties():
+    """The reference's own top_k_top_p_filtering on rows whose nucleus boundary cuts through a tie group: how MANY entries
+    survive is defined by the reference (which ones is up to its sort implementation)."""
+    from tests.cases import make_topp_tie_rows
+    l, tops = make_topp_tie_rows()
+    kept = []
+    for r in range(l.shape[0]):
+        out = ref_gen.top_k_top_p_filtering(l[r:r + 1].clone(), top_k=0, top_p=tops[r])
+        kept.append(int(torch.isfinite(out).sum()))
+    np.savez_compressed(os.path.join(HERE, "topp_ties.npz"), kept=np.array(kept, dtype=np.int64), top_p=np.array(tops, dtype=np.float64))
+    print("topp_ties: kept counts", kept)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
+    if not only or "topp_ties" in only:
+        run_topp_ties()
     for name, case in GPT_CASES.items():
         if only and name not in only:
             continue

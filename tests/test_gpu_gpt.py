@@ -309,6 +309,33 @@ def test_sampler_index_exact(dt, B, V, cfg, interval, step, temp, topk, greedy, 
     assert (seq[:, :step] == -1).all() and (seq[:, step + 1:] == -1).all()
 
 
+def test_sampler_topp_tie_groups_index_exact():
+    """top-p boundary inside a group of equal logits (tests/cases.make_topp_tie_rows; the kept count is pinned to the reference
+    in tests/golden/topp_ties.npz through the oracle): the kernel must keep exactly the oracle's subset -- the lowest-index ties
+    -- so every noise draw samples the oracle's token, and over many draws only kept entries ever appear."""
+    from tests.cases import make_topp_tie_rows
+    L, dev = _L(), _dev()
+    l, tops = make_topp_tie_rows()
+    V = l.shape[1]
+    g = torch.Generator().manual_seed(3)
+    ndraw = 48
+    for r in range(l.shape[0]):
+        kept = torch.isfinite(O.top_k_top_p_filtering(l[r:r + 1], top_k=0, top_p=tops[r])[0])
+        noise = torch.empty(ndraw, 1, V).exponential_(1, generator=g)
+        lg_d, nz_d = l[r:r + 1].contiguous().to(dev), noise.to(dev)
+        seq = torch.full((1, ndraw), -1, dtype=torch.int32, device=dev)
+        cur = torch.zeros(1, dtype=torch.int32, device=dev)
+        for j in range(ndraw):
+            state = torch.tensor([j, j], dtype=torch.int32, device=dev)
+            L.check(L.lib().lgen_sample(L.ptr(lg_d), L.ptr(nz_d), V, L.ptr(cur), L.ptr(seq), L.ptr(state), 1, V, ndraw, 0, 1.0, -1, 1.0, 0,
+                                        float(tops[r]), 0, L.F32, L.stream()), "sample")
+        got = seq[0].cpu().long()
+        ref = torch.stack([O.sample(l[r:r + 1], temperature=1.0, top_k=0, top_p=tops[r], sample_logits=True, noise=noise[j])[0].view(())
+                           for j in range(ndraw)])
+        assert bool(kept[got].all()), (r, "sampled a removed entry")
+        assert torch.equal(got, ref), (r, (got != ref).sum().item())
+
+
 @pytest.mark.parametrize("kind", ["constant", "plateau", "two_values", "huge_range"])
 def test_sampler_degenerate_rows(kind):
     """Rows the one-pass histogram cannot resolve (constant rows, thousands of equal values in the critical

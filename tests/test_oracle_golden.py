@@ -123,3 +123,22 @@ def test_oracle_edge_cases():
     assert torch.isfinite(f).all()
     fr = O.precompute_freqs_cis_2d(4, 64, 10000.0, 3)
     assert fr.shape == (3 + 16, 32, 2) and (fr[:3] == 0).all() and (fr[3, :, 0] == 1).all()
+
+
+def test_topp_tie_groups_match_reference_count():
+    """Nucleus boundary inside a group of equal logits: the reference keeps a sort-order prefix of the group; its SIZE is
+    pinned by tests/golden/topp_ties.npz (made by the reference's own top_k_top_p_filtering), the members are the lowest-index
+    ties (stable descending sort = the order torch's GPU sort gives the reference)."""
+    from tests.cases import make_topp_tie_rows
+    gold = load_golden("topp_ties")
+    l, tops = make_topp_tie_rows()
+    for r in range(l.shape[0]):
+        assert abs(tops[r] - gold["top_p"][r]) < 1e-12
+        out = O.top_k_top_p_filtering(l[r:r + 1], top_k=0, top_p=tops[r])[0]
+        kept = torch.isfinite(out)
+        assert int(kept.sum()) == int(gold["kept"][r]), (r, int(kept.sum()), int(gold["kept"][r]))
+        ties = (l[r] == 1.0).nonzero().flatten()
+        kt = ties[kept[ties]]
+        assert 0 < kt.numel() < ties.numel(), "the boundary must cut the tie group"
+        assert torch.equal(kt, ties[: kt.numel()])  # lowest indices first
+        assert bool(kept[l[r] > 1.0].all()) and not bool(kept[l[r] < 1.0].any())

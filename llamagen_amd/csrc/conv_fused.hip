@@ -298,6 +298,18 @@ __global__ __launch_bounds__(64 * NWV, NWV / 2) void conv_fused_kernel(ConvFArgs
     float* outb = a.out + (size_t)b * HW * a.Cout;
     const float* resb = a.res ? a.res + (size_t)b * HW * a.Cout : nullptr;
     float* red = (float*)smem;  // [WMW][BN/4][2] after the main loop (all LDS reads are behind the last barrier)
+    // All residual loads of the wave's tiles first (the halo / fragment registers are dead here): inside the store loop below each
+    // load would sit behind the previous tile's store (`out` and `res` may alias as far as the compiler knows), i.e. JN x JM
+    // dependent memory round trips per tile -- measured as 10 % of the kernel.
+    const bool res_fast = resb && !a.out_nchw && (nb + 1) * BN <= a.Cout;
+    float4 rres[JN][JM];
+    if (res_fast) {
+#pragma unroll
+        for (int j = 0; j < JN; ++j)
+#pragma unroll
+            for (int i = 0; i < JM; ++i)
+                rres[j][i] = *(const float4*)(resb + ((size_t)(y0 + wm * JM + i) * a.W + x0 + fr) * a.Cout + nb * BN + (wn * JN + j) * 16 + fg * 4);
+    }
 #pragma unroll
     for (int j = 0; j < JN; ++j) {
         const int nl = (wn * JN + j) * 16 + fg * 4;
@@ -323,7 +335,7 @@ __global__ __launch_bounds__(64 * NWV, NWV / 2) void conv_fused_kernel(ConvFArgs
             if (!a.out_nchw && n + 3 < a.Cout) {
                 const size_t o = p * a.Cout + n;
                 if (resb) {
-                    const float4 r = *(const float4*)(resb + o);
+                    const float4 r = res_fast ? rres[j][i] : *(const float4*)(resb + o);
                     v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
                 }
                 *(float4*)(outb + o) = make_float4(v[0], v[1], v[2], v[3]);

@@ -166,7 +166,10 @@ class SamplingPipeline:
         while True:
             for lane in self.lanes:  # batches start in submission order (-> RNG consumption order)
                 if not lane.busy and nxt < len(conds):
-                    lane.start(nxt, conds[nxt], max_new_tokens, decode_shape, gen_kw)
+                    # a callable is evaluated only now, so that a driver can draw its labels from the device generator in the
+                    # reference's order (labels of batch i, noise of batch i, labels of batch i+1, ...: sample_c2i_ddp.py:128-140)
+                    cond = conds[nxt]() if callable(conds[nxt]) else conds[nxt]
+                    lane.start(nxt, cond, max_new_tokens, decode_shape, gen_kw)
                     nxt += 1
             active = [lane for lane in self.lanes if lane.busy]
             if not active:

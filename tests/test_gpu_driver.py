@@ -58,3 +58,40 @@ def test_sample_c2i_driver_matches_oracle(tmp_path):
     grid = np.asarray(Image.open(res["path"]))
     assert grid.shape == (256 + 4, 3 * 258 + 2, 3) and grid.dtype == np.uint8
     np.testing.assert_array_equal(grid[2:258, 2:258], O.to_uint8_hwc(res["samples"][:1].cpu())[0].numpy())
+
+
+def test_sample_c2i_ddp_driver_equals_sequential_loop(tmp_path):
+    """examples/sample_c2i_ddp.py (world 1, 2 lanes in flight, 3 iterations of 2 images, resize 256 -> ... kept at 256) writes the
+    .npz the reference's loop would: labels and noise in the reference's RNG order, uint8 HWC, global index order."""
+    spec = importlib.util.spec_from_file_location("example_sample_c2i_ddp", os.path.join(ROOT, "examples", "sample_c2i_ddp.py"))
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    from llamagen_amd import generate
+    from llamagen_amd.postprocess import to_uint8_hwc
+    dev = torch.device("cuda:0")
+    lat = 16
+    gpt = GPT_models["GPT-B"](vocab_size=16384, block_size=lat * lat, num_classes=1000, cls_token_num=1, model_type="c2i")
+    gsd = synth_for_module(gpt, seed=41, lin_std=0.02)
+    torch.save({"model": gsd}, tmp_path / "c2i_B_256.pt")
+    vq = VQ_models["VQ-16"](codebook_size=16384, codebook_embed_dim=8)
+    vsd = synth_for_module(vq, seed=42)
+    torch.save({"model": vsd}, tmp_path / "vq.pt")
+    argv = ["--gpt-model", "GPT-B", "--gpt-ckpt", str(tmp_path / "c2i_B_256.pt"), "--vq-ckpt", str(tmp_path / "vq.pt"), "--image-size", "256",
+            "--image-size-eval", "256", "--precision", "bf16", "--global-seed", "3", "--cfg-scale", "2.0", "--top-k", "500",
+            "--per-proc-batch-size", "2", "--num-fid-samples", "5", "--sample-dir", str(tmp_path / "samples"), "--lanes", "2"]
+    path = ex.main(ex.build_parser().parse_args(argv))
+    arr = np.load(path)["arr_0"]
+    assert arr.shape == (5, 256, 256, 3) and arr.dtype == np.uint8 and "GPT-B-c2i_B_256-size-256-size-256-VQ-16-topk-500" in path
+    # the reference's loop, sequentially, on the same seed
+    gpt.load_state_dict(gsd, strict=False)
+    gpt = gpt.to(device=dev, dtype=torch.bfloat16).eval()
+    vq.load_state_dict(vsd)
+    vq = vq.to(dev).eval()
+    torch.manual_seed(3)  # rank_seed(3, 0, 1)
+    ref = []
+    for _ in range(3):
+        c = torch.randint(0, 1000, (2,), device=dev)
+        ids = generate(gpt, c, lat * lat, cfg_scale=2.0, cfg_interval=-1, temperature=1.0, top_k=500, top_p=1.0, sample_logits=True)
+        ref.append(to_uint8_hwc(vq.decode_code(ids, [2, 8, lat, lat])).cpu())
+    ref = torch.cat(ref).numpy()[:5]
+    np.testing.assert_array_equal(arr, ref)

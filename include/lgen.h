@@ -26,10 +26,14 @@
 extern "C" {
 #endif
 
-#define LGEN_ABI_VERSION 4
+#define LGEN_ABI_VERSION 5
 #define LGEN_BF16 0
 #define LGEN_F32 1
 #define LGEN_F16 2   /* fp16 storage: BF16's layouts (KC = 32, EPL = 8), IEEE half rounding, v_mfma_f32_16x16x32_f16 */
+
+/* Row statistics of the fused RMSNorm: ssq arrays are [MTs*16 rows][LGEN_SSQ_STRIDE] fp32; row m holds `parts` partial sums of
+ * squares (one per 16 columns of the producer: parts = d/16), contiguous, so a consumer reads them as a few 16-byte loads. */
+#define LGEN_SSQ_STRIDE 256
 
 #define LGEN_ERR_BAD_ARG (-1)
 #define LGEN_ERR_UNSUPPORTED (-2)
@@ -48,14 +52,14 @@ int lgen_abi_version(void);
 
 /* nn.Embedding gather (gpt.py:78-83 LabelEmbedder / :351 tok_embeddings) -> packed residual stream.
  * table [rows][d] storage dtype, idx int32 [M] (device), hp = XP[d/KC][MTs]; ssq_out (nullable):
- * [d/KC][MTs*16] fp32 partial row sums of squares for the first fused RMSNorm; state_advance (nullable):
+ * [MTs*16][LGEN_SSQ_STRIDE] fp32, d/16 partial row sums of squares per row, for the first fused RMSNorm; state_advance (nullable):
  * device {pos, step}, both incremented before the rest of the decode step reads them (the
  * `input_pos += 1` of generate.py:118). */
 int lgen_embed_pack(const void* table, const int* idx, void* hp, float* ssq_out, int* state_advance, int M, int MTs,
                     int d, int rows, int dtype, void* stream);
 
 /* Row sums of squares of an already packed residual stream hp = XP[d/KC][MTs] (t2i prefix rows produced
- * by the CaptionEmbedder MLP): ssq_out [d/KC][MTs*16] fp32, the ssq_in of a fused RMSNorm. */
+ * by the CaptionEmbedder MLP): ssq_out [MTs*16][LGEN_SSQ_STRIDE] fp32 (d/16 partials per row), the ssq_in of a fused RMSNorm. */
 int lgen_ssq_pack(const void* hp, float* ssq_out, int MTs, int d, int dtype, void* stream);
 
 /* RMSNorm.forward (gpt.py:143-148) on XP -> XP, fp32 math, two storage roundings. */
@@ -67,8 +71,8 @@ int lgen_rmsnorm(const void* hp, const void* weight, void* xnp, int MTs, int d, 
  * RMSNorm fusion (gpt.py:137-148, the norm that precedes wqkv / w1,w3 / output in gpt.py:253-256,367):
  *   norm_w != NULL (ROWS, SWIGLU): x is the un-normalised residual stream and the kernel applies
  *     rnd(rnd(x * rsqrt(mean(x^2) + eps)) * norm_w) to the operand on the fly; mean(x^2) comes from
- *     ssq_in[ssq_parts][MTs*16] fp32 partial row sums of squares (summed in a fixed order);
- *   ssq_out != NULL (RES only): also writes ssq_out[N/16][MTs*16], the per-(16-column tile, row) sums of
+ *     ssq_in[MTs*16][LGEN_SSQ_STRIDE] fp32: ssq_parts partial row sums of squares per row (summed in a fixed order);
+ *   ssq_out != NULL (RES only): also writes ssq_out[row][N/16 partials], the per-(row, 16-column tile) sums of
  *     squares of the updated residual stream, i.e. the ssq_in (ssq_parts = N/16) of the next norm. */
 int lgen_gemm(const void* wp, const void* xp, void* out, int M, int MTs, int N, int K, int epilogue_kind, int dtype,
               int mt, int nt, int kw, const void* norm_w, const float* ssq_in, int ssq_parts, float eps,

@@ -17,7 +17,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblgen_hip.so")
 BF16, F32, F16 = 0, 1, 2
 EPI_ROWS, EPI_PACKED, EPI_GELU, EPI_RES, EPI_SWIGLU, EPI_QKV = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 4
+ABI_VERSION = 5
+SSQ_STRIDE = 256  # LGEN_SSQ_STRIDE: floats per row of a fused-RMSNorm statistics array
 ERR_UNSUPPORTED = -2
 
 _c = ctypes

@@ -16,8 +16,8 @@ struct GemmArgs {
     const int* pos_ptr;  // QKV: position of this token: device scalar, or one per row (pos_stride = 1)
     int pos_stride;      // QKV: 0 = all rows at *pos_ptr; 1 = row m at pos_ptr[m] (continuous batching: every row its own position)
     const uint4* nw;     // NORM: RMSNorm weight [K] storage dtype
-    const float* ssq_in; // NORM: [parts][MTs*16] partial sums of squares of the x rows
-    float* ssq_out;      // RES: [N/16][MTs*16] partial sums of squares of the new rows (nullable)
+    const float* ssq_in; // NORM: [MTs*16][LGEN_SSQ_STRIDE], `parts` partial sums of squares per x row
+    float* ssq_out;      // RES: [MTs*16][LGEN_SSQ_STRIDE], N/16 partials per new row (nullable)
     int N, KCH, MTs, M;
     int d, hd, hdp, H, S8;
     int kvs;             // QKV: elements between consecutive cache rows (hdp, or 2*hdp for an interleaved K|V slab)
@@ -56,6 +56,83 @@ LGEN_DEV void prefetch_retire(const char* base, unsigned token) {
     if (base) asm volatile("s_waitcnt vmcnt(0)" ::"v"(token) : "memory");
 }
 
+// This lane's share of one row's sum of squares: lane group q4 = lane >> 4 sums a contiguous quarter of the row's `parts`
+// partials; the caller adds the four groups (xor 16, 32).  Fast path (parts a multiple of 16, <= 128: every registry model):
+// up to 8 UNCONDITIONAL 16-byte loads, so that the caller can issue them -- and its weight loads behind them -- without a
+// single wait in between (the round-1 form, a runtime-length loop of 4-byte loads, made the compiler wait for every group of
+// four before the weight stream was even requested: 2-3 us per fused-norm GEMM).
+template <int NV>
+struct SsqLoads { float4 v[NV]; int n4; bool fast; };
+// NV (16-byte loads a lane keeps in flight per m-tile) shrinks with the m-tiles of a workgroup: 8 / 4 / 2 for MT = 1 / 2 / >= 4,
+// i.e. the no-wait form covers d <= 2048 / 1024 / 512; wider rows take the strided loop below (correct, with waits).
+template <int MT>
+constexpr int ssq_nv() { return MT == 1 ? 8 : (MT == 2 ? 4 : 2); }
+template <int NV>
+LGEN_DEV SsqLoads<NV> ssq_issue(const float* ssq_in, int parts, int row, int lane) {
+    SsqLoads<NV> r;
+    r.fast = (parts & 15) == 0 && parts <= 16 * NV;
+    r.n4 = parts >> 4;                       // float4 loads per lane group
+    const int q4 = lane >> 4;
+    const float4* p = (const float4*)(ssq_in + (size_t)row * LGEN_SSQ_STRIDE) + q4 * r.n4;
+    if (r.fast) {
+        constexpr int H = NV > 4 ? 4 : NV;
+#pragma unroll
+        for (int j = 0; j < H; ++j) r.v[j] = p[j < r.n4 ? j : 0];
+        if constexpr (NV > 4) {
+            if (r.n4 > 4) {
+#pragma unroll
+                for (int j = 4; j < NV; ++j) r.v[j] = p[j < r.n4 ? j : 0];
+            }
+        }
+    }
+    return r;
+}
+template <int NV>
+LGEN_DEV float ssq_finish(const SsqLoads<NV>& r, const float* ssq_in, int parts, int row, int lane) {
+    float s = 0.f;
+    if (r.fast) {
+        constexpr int H = NV > 4 ? 4 : NV;
+#pragma unroll
+        for (int j = 0; j < H; ++j) s += j < r.n4 ? (r.v[j].x + r.v[j].y) + (r.v[j].z + r.v[j].w) : 0.f;
+        if constexpr (NV > 4) {
+            if (r.n4 > 4) {
+#pragma unroll
+                for (int j = 4; j < NV; ++j) s += j < r.n4 ? (r.v[j].x + r.v[j].y) + (r.v[j].z + r.v[j].w) : 0.f;
+            }
+        }
+    } else {  // any other width (d = 800 test model, wide rows): strided scalar loop
+        const float* p = ssq_in + (size_t)row * LGEN_SSQ_STRIDE;
+        for (int q = lane >> 4; q < parts; q += 4) s += p[q];
+    }
+    return s;
+}
+
+// Position of the rows a lane works on (QKV epilogue: RoPE angles, KV-cache slot): one device scalar (generate(): every row at
+// the same position, a scalar-cache load) or one per row (continuous batching: a vector load, issued FIRST in the kernel so that
+// the dependent RoPE-table loads never wait behind the weight stream).
+template <int MT, int EPI>
+LGEN_DEV void load_row_pos(const GemmArgs& a, int mt0, int lane, int (&posr)[MT]) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) posr[i] = 0;
+    if constexpr (EPI == 5 /* EPI_QKV */) {
+        if (a.pos_stride) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) posr[i] = a.pos_ptr[(mt0 + i) * 16 + (lane & 15)];
+        } else {
+            const int p0 = *a.pos_ptr;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) posr[i] = p0;
+        }
+    }
+}
+template <int MT>
+LGEN_DEV int pick_pos(const int (&posr)[MT], int i) {  // posr[i] for a runtime i without indexing the register array
+    int p = 0;
+#pragma unroll
+    for (int k = 0; k < MT; ++k) p |= posr[k] & -(int)(i == k);  // (a select chain is turned back into an indexed load)
+    return p;
+}
+
 LGEN_DEV float silu_f(float x) { return x / (1.0f + expf(-x)); }
 LGEN_DEV float gelu_tanh_f(float x) {
     const float k0 = 0.7978845608028654f, k1 = 0.044715f;
@@ -78,7 +155,6 @@ LGEN_DEV uint4 epi_prefetch(const GemmArgs& a, int nt, int mt, int lane, int pos
             aux = *(const uint4*)((const float*)a.out + o);
         }
     } else if constexpr (EPI == EPI_QKV) {
-        if (a.pos_stride) pos = a.pos_ptr[(mt * 16 + r) * a.pos_stride];
         const int sec = n / a.d;
         if (sec < 2) {
             const int c = n - sec * a.d;
@@ -116,7 +192,7 @@ LGEN_DEV void epilogue(const GemmArgs& a, int nt, int mt, int lane, f32x4_t v, f
             float ss = ((h0 * h0 + h1 * h1) + h2 * h2) + h3 * h3;
             ss += __shfl_xor(ss, 16, 64);
             ss += __shfl_xor(ss, 32, 64);
-            if (lane < 16) a.ssq_out[(size_t)nt * (a.MTs * 16) + m] = ss;
+            if (lane < 16) a.ssq_out[(size_t)m * LGEN_SSQ_STRIDE + nt] = ss;
         }
     } else if constexpr (EPI == EPI_SWIGLU) {
         // nt is the w1 tile (even), v2 the matching w3 tile; output feature f = (nt/2)*16 + g*4
@@ -126,7 +202,6 @@ LGEN_DEV void epilogue(const GemmArgs& a, int nt, int mt, int lane, f32x4_t v, f
                D::rnd(silu_f(x0)) * y0, D::rnd(silu_f(x1)) * y1, D::rnd(silu_f(x2)) * y2, D::rnd(silu_f(x3)) * y3);
     } else if constexpr (EPI == EPI_QKV) {
         if (m >= a.M) return;
-        if (a.pos_stride) pos = a.pos_ptr[m * a.pos_stride];
         const int sec = n / a.d;
         const int c = n - sec * a.d;
         const int head = c / a.hd;

@@ -26,8 +26,8 @@ __global__ __launch_bounds__(512) void gemm_normpre_kernel(GemmArgs a) {
     const int nt0 = blockIdx.x * NT;
     const int mt0 = blockIdx.y * MT;
     const int k0 = w * CPW;
-    int pos = 0;
-    if constexpr (EPI == EPI_QKV) pos = *a.pos_ptr;
+    int posr[MT];
+    load_row_pos<MT, EPI>(a, mt0, lane, posr);
 
     const unsigned pf_token = prefetch_lines(a.pf, a.pf_bytes, (blockIdx.y * gridDim.x + blockIdx.x) * KW + w,
                                              gridDim.x * gridDim.y * KW, lane);
@@ -41,18 +41,9 @@ __global__ __launch_bounds__(512) void gemm_normpre_kernel(GemmArgs a) {
         for (int i = 0; i < MT; ++i) B[c][i] = xbase[(size_t)(k0 + c) * xstride + i * 64];
         WN[c] = a.nw[(size_t)(k0 + c) * 4 + (lane >> 4)];
     }
-    float ss[MT];
-    {
-        const int R = a.MTs * 16;
+    SsqLoads<ssq_nv<MT>()> sl[MT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const float* p = a.ssq_in + (size_t)(mt0 + i) * 16 + (lane & 15);
-            float s = 0.f;
-#pragma unroll 4
-            for (int q = lane >> 4; q < a.parts; q += 4) s += p[(size_t)q * R];
-            ss[i] = s;
-        }
-    }
+    for (int i = 0; i < MT; ++i) sl[i] = ssq_issue<ssq_nv<MT>()>(a.ssq_in, a.parts, (mt0 + i) * 16 + (lane & 15), lane);
     // 2. every weight chunk of this wave + the epilogue's memory operands
     uint4 A[CPW][NT];
     const uint4* wbase = a.wp + ((size_t)nt0 * a.KCH) * 64 + lane;
@@ -70,14 +61,14 @@ __global__ __launch_bounds__(512) void gemm_normpre_kernel(GemmArgs a) {
             const int u = w + q * KW;
             if (u < UNITS) {
                 const int j = u / MT, i = u - j * MT;
-                aux[q] = epi_prefetch<D, EPI>(a, nt0 + j, mt0 + i, lane, pos);
+                aux[q] = epi_prefetch<D, EPI>(a, nt0 + j, mt0 + i, lane, pick_pos<MT>(posr, i));
             }
         }
     }
     // 3. RMSNorm in registers (gpt.py:143-148), fixed-order statistics
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-        float s = ss[i];
+        float s = ssq_finish(sl[i], a.ssq_in, a.parts, (mt0 + i) * 16 + (lane & 15), lane);
         s += __shfl_xor(s, 16, 64);
         s += __shfl_xor(s, 32, 64);
         const float ri = 1.0f / sqrtf(s * a.inv_k + a.eps);
@@ -104,10 +95,10 @@ __global__ __launch_bounds__(512) void gemm_normpre_kernel(GemmArgs a) {
         for (int q = 0; q < UNITS; ++q) {
             if constexpr (EPI == EPI_SWIGLU) {
                 const int jp = q / MT, i = q - jp * MT;
-                epilogue<D, EPI>(a, nt0 + 2 * jp, mt0 + i, lane, acc[2 * jp][i], acc[(2 * jp + 1) % NT][i], aux[q], pos);
+                epilogue<D, EPI>(a, nt0 + 2 * jp, mt0 + i, lane, acc[2 * jp][i], acc[(2 * jp + 1) % NT][i], aux[q], pick_pos<MT>(posr, i));
             } else {
                 const int j = q / MT, i = q - j * MT;
-                epilogue<D, EPI>(a, nt0 + j, mt0 + i, lane, acc[j][i], acc[j][i], aux[q], pos);
+                epilogue<D, EPI>(a, nt0 + j, mt0 + i, lane, acc[j][i], acc[j][i], aux[q], pick_pos<MT>(posr, i));
             }
         }
         return;
@@ -135,11 +126,11 @@ __global__ __launch_bounds__(512) void gemm_normpre_kernel(GemmArgs a) {
         if (u < UNITS) {
             if constexpr (EPI == EPI_SWIGLU) {
                 const int jp = u / MT, i = u - jp * MT;
-                epilogue<D, EPI>(a, nt0 + 2 * jp, mt0 + i, lane, rsum((2 * jp) * MT + i), rsum((2 * jp + 1) * MT + i), aux[q], pos);
+                epilogue<D, EPI>(a, nt0 + 2 * jp, mt0 + i, lane, rsum((2 * jp) * MT + i), rsum((2 * jp + 1) * MT + i), aux[q], pick_pos<MT>(posr, i));
             } else {
                 const int j = u / MT, i = u - j * MT;
                 const f32x4_t v = rsum(u);
-                epilogue<D, EPI>(a, nt0 + j, mt0 + i, lane, v, v, aux[q], pos);
+                epilogue<D, EPI>(a, nt0 + j, mt0 + i, lane, v, v, aux[q], pick_pos<MT>(posr, i));
             }
         }
     }

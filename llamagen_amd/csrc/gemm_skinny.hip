@@ -57,8 +57,8 @@ __global__ __launch_bounds__((gemm_max_threads<MT, NT, NORM, EPI>())) void gemm_
     const int nt0 = blockIdx.x * NT;
     const int mt0 = blockIdx.y * MT;
     const int k0 = (int)(((long)a.KCH * w) / KW), k1 = (int)(((long)a.KCH * (w + 1)) / KW);
-    int pos = 0;
-    if constexpr (EPI == EPI_QKV) pos = *a.pos_ptr;
+    int posr[MT];
+    load_row_pos<MT, EPI>(a, mt0, lane, posr);
 
     const uint4* wbase = a.wp + ((size_t)nt0 * a.KCH) * 64 + lane;
     const uint4* xbase = a.xp + (size_t)mt0 * 64 + lane;
@@ -90,7 +90,7 @@ __global__ __launch_bounds__((gemm_max_threads<MT, NT, NORM, EPI>())) void gemm_
             const int u = w + q * KW;
             if (u < UNITS) {
                 const int j = u / MT, i = u - j * MT;
-                aux[q] = epi_prefetch<D, EPI>(a, nt0 + j, mt0 + i, lane, pos);
+                aux[q] = epi_prefetch<D, EPI>(a, nt0 + j, mt0 + i, lane, pick_pos<MT>(posr, i));
             }
         }
     }
@@ -98,13 +98,11 @@ __global__ __launch_bounds__((gemm_max_threads<MT, NT, NORM, EPI>())) void gemm_
     // 3. RMSNorm row scales from the producer's partial sums of squares (fixed order)
     float ri[MT];
     if constexpr (NORM) {
-        const int R = a.MTs * 16;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-            const float* p = a.ssq_in + (size_t)(mt0 + i) * 16 + (lane & 15);
-            float s = 0.f;
-#pragma unroll 4
-            for (int q = lane >> 4; q < a.parts; q += 4) s += p[(size_t)q * R];
+            const int row = (mt0 + i) * 16 + (lane & 15);
+            const SsqLoads<4> sl = ssq_issue<4>(a.ssq_in, a.parts, row, lane);
+            float s = ssq_finish(sl, a.ssq_in, a.parts, row, lane);
             s += __shfl_xor(s, 16, 64);
             s += __shfl_xor(s, 32, 64);
             ri[i] = 1.0f / sqrtf(s * a.inv_k + a.eps);
@@ -156,10 +154,10 @@ __global__ __launch_bounds__((gemm_max_threads<MT, NT, NORM, EPI>())) void gemm_
         for (int q = 0; q < UNITS; ++q) {
             if constexpr (EPI == EPI_SWIGLU) {
                 const int jp = q / MT, i = q - jp * MT;
-                epilogue<D, EPI>(a, nt0 + 2 * jp, mt0 + i, lane, acc[2 * jp][i], acc[(2 * jp + 1) % NT][i], aux[q], pos);
+                epilogue<D, EPI>(a, nt0 + 2 * jp, mt0 + i, lane, acc[2 * jp][i], acc[(2 * jp + 1) % NT][i], aux[q], pick_pos<MT>(posr, i));
             } else {
                 const int j = q / MT, i = q - j * MT;
-                epilogue<D, EPI>(a, nt0 + j, mt0 + i, lane, acc[j][i], acc[j][i], aux[q], pos);
+                epilogue<D, EPI>(a, nt0 + j, mt0 + i, lane, acc[j][i], acc[j][i], aux[q], pick_pos<MT>(posr, i));
             }
         }
         return;
@@ -187,11 +185,11 @@ __global__ __launch_bounds__((gemm_max_threads<MT, NT, NORM, EPI>())) void gemm_
         if (u < UNITS) {
             if constexpr (EPI == EPI_SWIGLU) {
                 const int jp = u / MT, i = u - jp * MT;
-                epilogue<D, EPI>(a, nt0 + 2 * jp, mt0 + i, lane, rsum((2 * jp) * MT + i), rsum((2 * jp + 1) * MT + i), aux[q], pos);
+                epilogue<D, EPI>(a, nt0 + 2 * jp, mt0 + i, lane, rsum((2 * jp) * MT + i), rsum((2 * jp + 1) * MT + i), aux[q], pick_pos<MT>(posr, i));
             } else {
                 const int j = u / MT, i = u - j * MT;
                 const f32x4_t v = rsum(u);
-                epilogue<D, EPI>(a, nt0 + j, mt0 + i, lane, v, v, aux[q], pos);
+                epilogue<D, EPI>(a, nt0 + j, mt0 + i, lane, v, v, aux[q], pick_pos<MT>(posr, i));
             }
         }
     }
@@ -299,6 +297,7 @@ extern "C" int lgen_gemm(const void* wp, const void* xp, void* out, int M, int M
                          float eps, float* ssq_out, void* stream) {
     const int kcsz = dtype != LGEN_F32 ? 32 : 16;
     if (N % 16 || K % kcsz || M > MTs * 16) return LGEN_ERR_BAD_ARG;
+    if ((norm_w && (ssq_parts < 1 || ssq_parts > LGEN_SSQ_STRIDE)) || (ssq_out && N / 16 > LGEN_SSQ_STRIDE)) return LGEN_ERR_BAD_ARG;
     GemmArgs a{};
     a.wp = (const uint4*)wp; a.xp = (const uint4*)xp; a.out = out;
     a.N = N; a.KCH = K / kcsz; a.MTs = MTs; a.M = M;
@@ -325,6 +324,7 @@ static int qkv_rope_impl(const void* wp, const void* xp, void* q_out, void* k_ca
     const int kcsz = dtype != LGEN_F32 ? 32 : 16;
     if (d % kcsz || (3 * d) % 16 || hd % 4 || d != n_head * hd || M > MTs * 16 || pos_stride < 0 || pos_stride > 1)
         return LGEN_ERR_BAD_ARG;
+    if (norm_w && (ssq_parts < 1 || ssq_parts > LGEN_SSQ_STRIDE)) return LGEN_ERR_BAD_ARG;
     GemmArgs a{};
     a.wp = (const uint4*)wp; a.xp = (const uint4*)xp; a.out = q_out; a.kc = k_cache; a.vc = v_cache;
     a.freqs = freqs; a.pos_ptr = pos_ptr; a.pos_stride = pos_stride;

@@ -8,11 +8,29 @@
 
 // ---------------------------------------------------------------------------------------------
 // embedding gather: hp[k-chunk][mt][lane] <- table[idx[m]][k..]   (16 B per thread), plus
-//   * ssq_out[kc][MTs*16]: per-(k-chunk, row) sums of squares = the partials the first fused
+//   * ssq_out[row][LGEN_SSQ_STRIDE]: per-(row, 16 columns) sums of squares = the partials the first fused
 //     RMSNorm (gemm_skinny.hip NORM prologue) sums in a fixed order
 //   * state advance: (pos, step) += 1 before anything of this decode step reads them (the sampler
 //     of the previous step is complete at this kernel's launch boundary)
 // ---------------------------------------------------------------------------------------------
+// one 16-byte chunk piece per lane -> this row's partial sums of squares, one per 16 columns (ssq[row][LGEN_SSQ_STRIDE]): a
+// 2-byte chunk (KC = 32) yields two partials (lane groups {0,1} and {2,3}), an fp32 chunk (KC = 16) one
+template <typename D>
+LGEN_DEV void ssq_store(const uint4& v, float* ssq_out, int kc, int m, int lane) {
+    float f[D::EPL];
+    D::unpack(v, f);
+    float ss = 0.f;
+#pragma unroll
+    for (int e = 0; e < D::EPL; ++e) ss += f[e] * f[e];
+    ss += __shfl_xor(ss, 16, 64);
+    if constexpr (D::KC == 32) {
+        if ((lane & 16) == 0) ssq_out[(size_t)m * LGEN_SSQ_STRIDE + 2 * kc + (lane >> 5)] = ss;
+    } else {
+        ss += __shfl_xor(ss, 32, 64);
+        if (lane < 16) ssq_out[(size_t)m * LGEN_SSQ_STRIDE + kc] = ss;
+    }
+}
+
 template <typename D>
 __global__ __launch_bounds__(256) void embed_pack_kernel(const uint4* __restrict__ table, const int* __restrict__ idx,
                                                          uint4* __restrict__ hp, float* __restrict__ ssq_out,
@@ -42,22 +60,13 @@ __global__ __launch_bounds__(256) void embed_pack_kernel(const uint4* __restrict
             v = tb[((size_t)row * d + kc * D::KC + (lane >> 4) * D::EPL) / D::EPL];
         }
         hp[t] = v;
-        if (ssq_out) {
-            float f[D::EPL];
-            D::unpack(v, f);
-            float ss = 0.f;
-#pragma unroll
-            for (int e = 0; e < D::EPL; ++e) ss += f[e] * f[e];
-            ss += __shfl_xor(ss, 16, 64);
-            ss += __shfl_xor(ss, 32, 64);
-            if (lane < 16) ssq_out[(size_t)kc * (MTs * 16) + m] = ss;
-        }
+        if (ssq_out) ssq_store<D>(v, ssq_out, kc, m, lane);
     }
 }
 
 extern "C" int lgen_embed_pack(const void* table, const int* idx, void* hp, float* ssq_out, int* state_advance, int M,
                                int MTs, int d, int rows, int dtype, void* stream) {
-    if (M > MTs * 16 || d % 32) return LGEN_ERR_BAD_ARG;
+    if (M > MTs * 16 || d % 32 || (ssq_out && d / 16 > LGEN_SSQ_STRIDE)) return LGEN_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == LGEN_BF16) {
         int total = (d / 32) * MTs * 64;
@@ -106,7 +115,7 @@ extern "C" int lgen_embed_rows(const void* tok_table, const void* cls_table, con
 }
 
 // Row sums of squares of an already packed residual stream (t2i prefix rows enter the decode loop
-// from the CaptionEmbedder MLP, not from an embedding gather): ssq_out[kc][MTs*16].
+// from the CaptionEmbedder MLP, not from an embedding gather): ssq_out[row][LGEN_SSQ_STRIDE], d/16 partials per row.
 template <typename D>
 __global__ __launch_bounds__(256) void ssq_pack_kernel(const uint4* __restrict__ hp, float* __restrict__ ssq_out, int total,
                                                        int MTs) {
@@ -114,20 +123,13 @@ __global__ __launch_bounds__(256) void ssq_pack_kernel(const uint4* __restrict__
         const int lane = t & 63;
         const int mt = (t >> 6) % MTs;
         const int kc = (t >> 6) / MTs;
-        float f[D::EPL];
-        D::unpack(hp[t], f);
-        float ss = 0.f;
-#pragma unroll
-        for (int e = 0; e < D::EPL; ++e) ss += f[e] * f[e];
-        ss += __shfl_xor(ss, 16, 64);
-        ss += __shfl_xor(ss, 32, 64);
-        if (lane < 16) ssq_out[(size_t)kc * (MTs * 16) + mt * 16 + lane] = ss;
+        ssq_store<D>(hp[t], ssq_out, kc, mt * 16 + (lane & 15), lane);
     }
 }
 
 extern "C" int lgen_ssq_pack(const void* hp, float* ssq_out, int MTs, int d, int dtype, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    if (d % 32 || !ssq_out) return LGEN_ERR_BAD_ARG;
+    if (d % 32 || !ssq_out || d / 16 > LGEN_SSQ_STRIDE) return LGEN_ERR_BAD_ARG;
     if (dtype == LGEN_BF16) {
         int total = (d / 32) * MTs * 64;
         hipLaunchKernelGGL(ssq_pack_kernel<BF16>, dim3((total + 255) / 256), dim3(256), 0, st, (const uint4*)hp, ssq_out, total, MTs);

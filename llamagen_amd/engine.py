@@ -159,7 +159,9 @@ class DecodeEngine:
         self.gp = z(self.F // self.kc, mts, 64, self.epl)
         self.qbuf = z(mts * 16, self.H, self.hdp)            # row-major q (zero pad lanes stay zero)
         self.logits = z(mts * 16, self.V)                    # row-major, storage dtype (gpt.py:368)
-        self.ssq = z(max(self.d // 16, 1), mts * 16, dtype=torch.float32)  # partial row sums of squares (fused RMSNorm)
+        if self.d // 16 > L.SSQ_STRIDE:
+            raise ValueError(f"dim {self.d} exceeds the fused-RMSNorm statistics row ({L.SSQ_STRIDE} x 16 columns)")
+        self.ssq = z(mts * 16, L.SSQ_STRIDE, dtype=torch.float32)  # per row: d/16 partial sums of squares (fused RMSNorm)
         self.ssq_parts = 0
         self.noise = None            # [N][B][V] fp32 Exp(1) draws of one generate() (allocated on demand)
         self.cur_tok = z(mts * 16, dtype=torch.int32)
@@ -344,14 +346,14 @@ class DecodeEngine:
         L.check(self.lib.lgen_embed_pack(L.ptr(table), L.ptr(idx), L.ptr(self.hp), L.ptr(self.ssq) if self.fuse_norm else 0,
                                          L.ptr(self.state) if advance else 0, self.B2, self.MTs, self.d, table.shape[0],
                                          self.dt, L.stream()), "embed_pack")
-        self.ssq_parts = self.d // self.kc
+        self.ssq_parts = self.d // 16
 
     def _set_residual(self, rows: torch.Tensor):
         """Residual stream <- given rows [B2, d] (t2i prefix tokens from the CaptionEmbedder MLP)."""
         self.hp.copy_(pack_act(rows.contiguous(), self.MTs).view_as(self.hp))
         if self.fuse_norm:
             L.check(self.lib.lgen_ssq_pack(L.ptr(self.hp), L.ptr(self.ssq), self.MTs, self.d, self.dt, L.stream()), "ssq_pack")
-        self.ssq_parts = self.d // self.kc
+        self.ssq_parts = self.d // 16
 
     def _sample(self, B, sp):
         """CFG mix + top-k + softmax + argmax(p/q) for the token at step = state[1]; q = noise[step]."""

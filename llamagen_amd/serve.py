@@ -89,7 +89,7 @@ class ContinuousBatcher:
         L.check(lib.lgen_embed_rows(L.ptr(e.tok_emb), L.ptr(e.cls_emb), L.ptr(e.cur_tok), L.ptr(self.cond), L.ptr(self.row_pos),
                                     L.ptr(e.hp), L.ptr(e.ssq) if e.fuse_norm else 0, self.B2, e.MTs, e.d, e.tok_emb.shape[0],
                                     e.cls_emb.shape[0], e.dt, L.stream()), "embed_rows")
-        e.ssq_parts = e.d // e.kc
+        e.ssq_parts = e.d // 16
         e._layers_and_logits()
         L.check(lib.lgen_sample_rows(L.ptr(e.logits), L.ptr(self.noise), L.ptr(e.cur_tok), L.ptr(self.seq), L.ptr(self.row_step),
                                      L.ptr(self.row_pos), self.N, self.B, e.V, self.N, 1 if self.use_cfg else 0, sp["cfg_scale"],

@@ -162,7 +162,7 @@ def test_fused_rmsnorm_chain(dt, M, d, F, tiles):
     wo, nw = _rand((d, d), dt, 33, 0.05), (1 + 0.1 * _rand((d,), torch.float32, 34)).to(dt)
     w1, w3 = _rand((F, d), dt, 35, 0.05), _rand((F, d), dt, 36, 0.05)
     wout = _rand((256, d), dt, 37, 0.05)
-    ssq = torch.full((d // 16, R), float("nan"), device=dev)
+    ssq = torch.full((R, L.SSQ_STRIDE), float("nan"), device=dev)  # [row][d/16 partials], include/lgen.h LGEN_SSQ_STRIDE
     hp, ap = pack_act(h0.to(dev), mts), pack_act(a_in.to(dev), mts)
     wop, nw_d = pack_weight(wo.to(dev)), nw.to(dev)
     # 1. producer: h = h0 + wo(a), ssq partials per 16-column tile
@@ -171,8 +171,8 @@ def test_fused_rmsnorm_chain(dt, M, d, F, tiles):
     h_ref = O._rnd(h0.float() + O.linear(a_in.float(), wo.float(), dt), dt)
     h_got = unpack_act(hp, M).float().cpu()
     _close(h_got, h_ref, dt, "res", mag=O.linear(a_in.float(), wo.float(), dt))
-    ss_ref = (h_got.double() ** 2).reshape(M, d // 16, 16).sum(-1).t()  # partials of what the kernel itself stored
-    np.testing.assert_allclose(ssq[:, :M].cpu().numpy(), ss_ref.float().numpy(), rtol=2e-6, atol=1e-30)
+    ss_ref = (h_got.double() ** 2).reshape(M, d // 16, 16).sum(-1)  # partials of what the kernel itself stored
+    np.testing.assert_allclose(ssq[:M, :d // 16].cpu().numpy(), ss_ref.float().numpy(), rtol=2e-6, atol=1e-30)
     # 2. consumers read h (as stored) through the fused norm
     xn_ref = O.rms_norm(h_got, nw, 1e-5, dt)
     w13 = torch.stack([pack_weight(w1.to(dev)), pack_weight(w3.to(dev))], dim=1).flatten(0, 1).contiguous()
@@ -186,12 +186,12 @@ def test_fused_rmsnorm_chain(dt, M, d, F, tiles):
     L.check(lib.lgen_gemm(L.ptr(woutp), L.ptr(hp), L.ptr(rows), M, mts, 256, d, L.EPI_ROWS, code, mt, nt, kw, L.ptr(nw_d),
                           L.ptr(ssq), d // 16, 1e-5, 0, L.stream()), "norm+rows")
     _close(rows[:M], O.linear(xn_ref, wout.float(), dt), dt, "norm+rows", frac_ulp1=0.05)
-    # 3. ssq_pack / embed produce the same statistic in d/KC parts
-    ssq2 = torch.full((d // kc, R), float("nan"), device=dev)
+    # 3. ssq_pack / embed produce the same statistic (their own d/16 partials)
+    ssq2 = torch.full((R, L.SSQ_STRIDE), float("nan"), device=dev)
     L.check(lib.lgen_ssq_pack(L.ptr(hp), L.ptr(ssq2), mts, d, code, L.stream()), "ssq_pack")
-    np.testing.assert_allclose(ssq2[:, :M].sum(0).cpu().numpy(), (h_got.double() ** 2).sum(-1).float().numpy(), rtol=1e-5)
+    np.testing.assert_allclose(ssq2[:M, :d // 16].sum(1).cpu().numpy(), (h_got.double() ** 2).sum(-1).float().numpy(), rtol=1e-5)
     L.check(lib.lgen_gemm(L.ptr(woutp), L.ptr(hp), L.ptr(rows), M, mts, 256, d, L.EPI_ROWS, code, mt, nt, kw, L.ptr(nw_d),
-                          L.ptr(ssq2), d // kc, 1e-5, 0, L.stream()), "norm+rows (ssq_pack parts)")
+                          L.ptr(ssq2), d // 16, 1e-5, 0, L.stream()), "norm+rows (ssq_pack parts)")
     _close(rows[:M], O.linear(xn_ref, wout.float(), dt), dt, "norm+rows 2", frac_ulp1=0.05)
     table = _rand((50, d), dt, 38)
     idx = torch.randint(0, 50, (M,), generator=torch.Generator().manual_seed(39)).to(torch.int32)
@@ -202,7 +202,7 @@ def test_fused_rmsnorm_chain(dt, M, d, F, tiles):
     assert state.cpu().tolist() == [8, 4]
     e_ref = table[idx.long()].float()
     assert torch.equal(unpack_act(hp, M).float().cpu(), e_ref)
-    np.testing.assert_allclose(ssq2[:, :M].sum(0).cpu().numpy(), (e_ref.double() ** 2).sum(-1).float().numpy(), rtol=1e-5)
+    np.testing.assert_allclose(ssq2[:M, :d // 16].sum(1).cpu().numpy(), (e_ref.double() ** 2).sum(-1).float().numpy(), rtol=1e-5)
 
 
 @pytest.mark.parametrize("dt", DTYPES)

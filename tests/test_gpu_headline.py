@@ -178,14 +178,14 @@ def test_qkv_fused_norm_rope_append_vs_oracle(d, H, pos):
     nw = (1 + 0.1 * _rand((d,), torch.float32, 43)).to(dt)
     freqs = precompute_freqs_cis_2d(grid, hd, 10000.0, 1)
     xp, wp, nw_d, fr_d = pack_act(x.to(dev), mts), pack_weight(w.to(dev)), nw.to(dev), freqs.to(dev)
-    ssq = torch.full((d // 32, mts * 16), float("nan"), device=dev)
+    ssq = torch.full((mts * 16, L.SSQ_STRIDE), float("nan"), device=dev)
     L.check(lib.lgen_ssq_pack(L.ptr(xp), L.ptr(ssq), mts, d, L.BF16, L.stream()), "ssq_pack")
     kc = torch.zeros(M, H, S8, 64, dtype=dt, device=dev)
     vc = torch.zeros(M, H, S8, 64, dtype=dt, device=dev)
     q = torch.zeros(mts * 16, H, 64, dtype=dt, device=dev)
     state = torch.tensor([pos, 0], dtype=torch.int32, device=dev)
     L.check(lib.lgen_gemm_qkv_rope(L.ptr(wp), L.ptr(xp), L.ptr(q), L.ptr(kc), L.ptr(vc), L.ptr(fr_d), L.ptr(state), M, mts, d, H,
-                                   hd, 64, S8, 0, L.BF16, 1, 4, 8, L.ptr(nw_d), L.ptr(ssq), d // 32, 1e-5, L.stream()), "qkv fused")
+                                   hd, 64, S8, 0, L.BF16, 1, 4, 8, L.ptr(nw_d), L.ptr(ssq), d // 16, 1e-5, L.stream()), "qkv fused")
     xn = O.rms_norm(x.float(), nw, 1e-5, dt)
     qkv = O.linear(xn, w.float(), dt)
     xq, xk, xv = qkv.split([d, d, d], dim=-1)

@@ -61,7 +61,7 @@ def main(name="GPT-L", B=32, img=384):
     report("advance_state (1 thread)", lambda: [lib.lgen_advance_state(L.ptr(e.state), st()) for _ in range(100)], 100)
     e.state.zero_()
     report("embed_pack (+ssq)", lambda: [e._embed(e.tok_emb, e.cur_tok) for _ in range(50)], 50)
-    e.ssq_parts = d // e.kc
+    e.ssq_parts = d // 16
     for kind, tiles_list in {
         "qkv": [(1, 4, 8)],
         "wo": [(1, 1, 8)],

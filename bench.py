@@ -8,10 +8,11 @@
 
 One "step" = one pass of the hot path over one batch of 32 images per GPU (synthetic class labels,
 random-init weights of the real architecture with output.weight re-randomised, bf16 GPT + fp32-class
-VQ decoder), inputs resident in HBM.  Consecutive steps are independent batches, so `--lanes` (default: 1..3, chosen from K)
-of them are kept in flight per GPU on separate HIP streams (llamagen_amd/pipeline.py: the decode chain
-is latency-bound, two chains interleave on the chip); all K timed steps start and finish inside the
-timed region.  N > 1 shards independent images over ranks (weak scaling, no collective during
+VQ decoder), inputs resident in HBM.  Consecutive steps are independent batches, so `--batches-per-chain` (default 2) of
+them share one decode chain (their rows are concatenated: 128 rows with CFG; every image is what its own generate() call
+would produce) and `--lanes` chains (default: 1..3, chosen from K) are kept in flight per GPU on separate HIP streams
+(llamagen_amd/pipeline.py: the decode chain is latency-bound, chains interleave on the chip); all K timed steps start and
+finish inside the timed region.  N > 1 shards independent images over ranks (weak scaling, no collective during
 generation) and ends every step with ONE RCCL gather of the decoded batch to rank 0.  Rank 0 prints
 one JSON line with `roofline` (dominant kernel = decode attention, measured live with HIP events on
 its launch stream) and `cpu_baseline` (the CPU oracle timed on a bounded sample).
@@ -250,8 +251,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--lanes", type=int, default=0, help="batches in flight per GPU (llamagen_amd/pipeline.py); "
+    ap.add_argument("--lanes", type=int, default=0, help="decode chains in flight per GPU (llamagen_amd/pipeline.py); "
                                                          "0 = pick 1..3 from the step count")
+    ap.add_argument("--batches-per-chain", type=int, default=2, help="consecutive steps (batches of 32) that share one decode chain")
     ap.add_argument("--steps-per-turn", type=int, default=1, help="decode steps a lane enqueues per scheduler turn")
     ap.add_argument("--vq-own-stream", action="store_true", help="decode images on a separate shared stream (measured slower)")
     ap.add_argument("--lane-cu-mask", action="store_true", help="experiment: every lane's stream owns 1/lanes of the CUs")
@@ -275,14 +277,16 @@ def main():
     torch.manual_seed(ldist.rank_seed(0, rank, world))  # per-rank labels / sampling noise only
     skw = dict(cfg_scale=CFG, cfg_interval=-1, temperature=1.0, top_k=TOPK, top_p=1.0, sample_logits=True)
     N = LAT * LAT
+    bpc = max(1, args.batches_per_chain)
+    chains = (args.steps + bpc - 1) // bpc
     if args.lanes <= 0:
-        # k batches in flight take ~T_k (measured, relative to one batch alone: 1, 1.44, 2.02); a run of K steps on L
-        # lanes costs floor(K/L) * T_L + T_(K mod L): use the cheapest L
-        T = {0: 0.0, 1: 1.0, 2: 1.44, 3: 2.02}
-        args.lanes = min((1, 2, 3), key=lambda l: (args.steps // l) * T[l] + T[args.steps % l])
+        # k chains in flight take ~T_k (measured, relative to one chain alone: 1, 1.44, 2.02 at 64 rows; 1, 1.5, 2.1 at 128);
+        # a run of C chains on L lanes costs floor(C/L) * T_L + T_(C mod L): use the cheapest L
+        T = {0: 0.0, 1: 1.0, 2: 1.44, 3: 2.02} if bpc == 1 else {0: 0.0, 1: 1.0, 2: 1.5, 3: 2.1}
+        args.lanes = min((1, 2, 3), key=lambda l: (chains // l) * T[l] + T[chains % l])
     pipe = SamplingPipeline(gpt, vq, lanes=args.lanes, steps_per_turn=args.steps_per_turn, vq_low_priority=args.vq_own_stream,
                             cu_partition=True if args.lane_cu_mask else None, vq_cus=args.vq_cus,
-                            lanes_avoid_vq_cus=args.lanes_avoid_vq_cus)
+                            lanes_avoid_vq_cus=args.lanes_avoid_vq_cus, batches_per_chain=bpc)
     pipe.prepare(BATCH, N, **skw)  # setup (like loading weights): KV slabs, workspaces, decode graphs per lane
     torch.cuda.synchronize()
 
@@ -315,42 +319,44 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # transparency: the same workload with ONE batch in flight (2 steps on lane 0), outside the timed region above
-    lane1 = None
+    # transparency: the same workload with ONE chain in flight (2 chains on lane 0), outside the timed region above
+    chain1 = None
     if args.lanes > 1:
         one = SamplingPipeline.__new__(SamplingPipeline)
-        one.dev, one.lanes, one.steps_per_turn, one.vq_stream = pipe.dev, pipe.lanes[:1], pipe.steps_per_turn, pipe.vq_stream
+        one.dev, one.lanes, one.steps_per_turn, one.vq_stream, one.bpc = pipe.dev, pipe.lanes[:1], pipe.steps_per_turn, pipe.vq_stream, bpc
         fence()
         t1 = time.perf_counter()
-        one.run([torch.randint(0, 1000, (BATCH,), device=dev) for _ in range(2)], N, **skw)
+        one.run([torch.randint(0, 1000, (BATCH,), device=dev) for _ in range(2 * bpc)], N, **skw)
         fence()
-        lane1 = BATCH * world * 2 / (time.perf_counter() - t1)
+        chain1 = BATCH * world * 2 * bpc / (time.perf_counter() - t1)
 
     if rank == 0:
         out = outs[-1]
         assert out is not None and out.shape[0] == BATCH * world and out.dtype == torch.uint8 and tuple(out.shape[1:]) == (IMG, IMG, 3)
         assert 8 < float(out.float().std()) < 128  # images, not a constant
         value = BATCH * world * args.steps / dt
-        if lane1 is None:
-            lane1 = value
+        if chain1 is None:
+            chain1 = value
         res = {"metric": "images/sec (whole node), LlamaGen-L 384px c2i", "value": round(value, 3), "unit": "images/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": "LlamaGen-L (GPT-L 343M) 384px c2i: generate 576 tokens (cfg 4.0, top-k 2000, "
                                       "bf16) + VQ-16 decode_code (fp32-class), batch 32 per step per GPU, random-init "
-                                      f"weights; {args.lanes} steps in flight per GPU on separate HIP streams",
+                                      f"weights; {bpc} consecutive steps share one decode chain ({2 * BATCH * bpc} rows with CFG), "
+                                      f"{args.lanes} chains in flight per GPU on separate HIP streams",
                           "global_batch": BATCH * world, "tokens_per_image": N, "parallelism": f"dp{world}",
-                          "steps_in_flight_per_gpu": args.lanes},
-               # the same workload with ONE generate() + decode_code() in flight at a time (no cross-batch overlap)
-               "images_per_s_with_one_step_in_flight": None if lane1 is None else round(lane1, 3)}
+                          "batches_per_chain": bpc, "chains_in_flight_per_gpu": args.lanes,
+                          "steps_in_flight_per_gpu": args.lanes * bpc},
+               # the same workload with ONE chain (bpc batches) in flight at a time (no cross-chain overlap)
+               "images_per_s_with_one_chain_in_flight": round(chain1, 3)}
         pmc = {}
         try:  # PMC passes of THIS round (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs; tools/pmc_summary.py)
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc.json")))
         except Exception:  # noqa: BLE001
             pass
         if not args.no_roofline:
-            sec, launches, per_pos = measure_attention(pipe.lanes[0].gpt, 2 * BATCH, N)
-            nbytes, nl = attention_bytes_per_generate(gpt.config, 2 * BATCH, N)
+            sec, launches, per_pos = measure_attention(pipe.lanes[0].gpt, 2 * BATCH * bpc, N)
+            nbytes, nl = attention_bytes_per_generate(gpt.config, 2 * BATCH * bpc, N)
             assert nl == launches, (nl, launches)
             ach = nbytes / sec / 1e9
             pa = pmc.get("attn_decode_kernel")
@@ -367,7 +373,7 @@ def main():
             nlay = gpt.config.n_layer
             tot_us = sum(us * (1 if k == "lm_head" else nlay) for k, (us, _) in gm.items())
             tot_b = sum(b * (1 if k == "lm_head" else nlay) for k, (_, b) in gm.items())
-            res["roofline_gemm"] = {"bound": "hbm", "kernel": "gemm_normpre_kernel / gemm_kernel (skinny weight-streaming GEMMs, M = 64)",
+            res["roofline_gemm"] = {"bound": "hbm", "kernel": f"gemm_normpre_kernel / gemm_kernel (skinny weight-streaming GEMMs, M = {2 * BATCH * bpc})",
                                     "achieved": round(tot_b / tot_us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                     "frac": round(tot_b / tot_us / 1e3 / HBM_PEAK_GBS, 4),
                                     "weight_bytes_per_step": int(tot_b), "us_per_step": round(tot_us, 1),
@@ -408,6 +414,19 @@ def main():
                                          "ms_per_decode_code": round(vq_ms, 2), "flop_per_image_fp32": 570.1e9, "mfma_passes": 3,
                                          "hipblaslt_bf16_gemm_8192_random_TFLOPs": round(lib_tf, 1),
                                          "frac_of_that_measured_ceiling": round(tf / lib_tf, 4)}
+        if world == 1 and bpc * args.lanes > 1:
+            # ... and with ONE generate() + decode_code() of 32 images in flight at a time (no cross-batch sharing at all): a fresh
+            # single-lane pipeline at 64 rows, set up and timed after everything above
+            pipe = None
+            gpt._engine = None
+            torch.cuda.empty_cache()
+            solo = SamplingPipeline(gpt, vq, lanes=1, batches_per_chain=1)
+            solo.prepare(BATCH, N, **skw)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            solo.run([torch.randint(0, 1000, (BATCH,), device=dev) for _ in range(2)], N, **skw)
+            torch.cuda.synchronize()
+            res["images_per_s_with_one_step_in_flight"] = round(BATCH * 2 / (time.perf_counter() - t1), 3)
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only (the other ranks would idle in the barrier)
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)

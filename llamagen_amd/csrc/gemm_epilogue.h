@@ -64,7 +64,7 @@ LGEN_DEV void prefetch_retire(const char* base, unsigned token) {
 template <int NV>
 struct SsqLoads { float4 v[NV]; int n4; bool fast; };
 // NV (16-byte loads a lane keeps in flight per m-tile) shrinks with the m-tiles of a workgroup: 8 / 4 / 2 for MT = 1 / 2 / >= 4,
-// i.e. the no-wait form covers d <= 2048 / 1024 / 512; wider rows take the strided loop below (correct, with waits).
+// i.e. the no-wait form covers d <= 2048 / 1024 / 512; wider rows are reduced before the weights are requested (ssq_rows_now).
 template <int MT>
 constexpr int ssq_nv() { return MT == 1 ? 8 : (MT == 2 ? 4 : 2); }
 template <int NV>
@@ -88,7 +88,7 @@ LGEN_DEV SsqLoads<NV> ssq_issue(const float* ssq_in, int parts, int row, int lan
     return r;
 }
 template <int NV>
-LGEN_DEV float ssq_finish(const SsqLoads<NV>& r, const float* ssq_in, int parts, int row, int lane) {
+LGEN_DEV float ssq_finish(const SsqLoads<NV>& r) {
     float s = 0.f;
     if (r.fast) {
         constexpr int H = NV > 4 ? 4 : NV;
@@ -100,11 +100,38 @@ LGEN_DEV float ssq_finish(const SsqLoads<NV>& r, const float* ssq_in, int parts,
                 for (int j = 4; j < NV; ++j) s += j < r.n4 ? (r.v[j].x + r.v[j].y) + (r.v[j].z + r.v[j].w) : 0.f;
             }
         }
-    } else {  // any other width (d = 800 test model, wide rows): strided scalar loop
-        const float* p = ssq_in + (size_t)row * LGEN_SSQ_STRIDE;
-        for (int q = lane >> 4; q < parts; q += 4) s += p[q];
     }
-    return s;
+    return s;  // !fast: the caller takes ssq_rows_now() instead
+}
+
+// The same statistic, reduced at once (the caller has NOT requested its weights yet, or does not mind waiting): this lane's
+// share of the sums of squares of rows (mt0 + i) * 16 + (lane & 15), i < MT.  parts a multiple of 16: 16-byte loads in rounds
+// of 4 per m-tile, every round's 4 * MT loads issued before its one wait (d = 1024: one round); else a scalar loop.
+template <int MT>
+LGEN_DEV void ssq_rows_now(const float* ssq_in, int parts, int mt0, int lane, float (&s)[MT]) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) s[i] = 0.f;
+    const float* base = ssq_in + (size_t)(mt0 * 16 + (lane & 15)) * LGEN_SSQ_STRIDE;
+    if ((parts & 15) == 0) {
+        const int n4 = parts >> 4;
+        const float4* p = (const float4*)base + (lane >> 4) * n4;
+        for (int c = 0; c < n4; c += 4) {
+            float4 v[MT][4];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[i][j] = p[(size_t)i * (16 * LGEN_SSQ_STRIDE / 4) + (c + j < n4 ? c + j : c)];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s[i] += c + j < n4 ? (v[i][j].x + v[i][j].y) + (v[i][j].z + v[i][j].w) : 0.f;
+        }
+    } else {
+        for (int q = lane >> 4; q < parts; q += 4) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) s[i] += base[(size_t)i * 16 * LGEN_SSQ_STRIDE + q];
+        }
+    }
 }
 
 // Position of the rows a lane works on (QKV epilogue: RoPE angles, KV-cache slot): one device scalar (generate(): every row at

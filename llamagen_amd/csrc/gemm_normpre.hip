@@ -44,6 +44,8 @@ __global__ __launch_bounds__(512) void gemm_normpre_kernel(GemmArgs a) {
     SsqLoads<ssq_nv<MT>()> sl[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) sl[i] = ssq_issue<ssq_nv<MT>()>(a.ssq_in, a.parts, (mt0 + i) * 16 + (lane & 15), lane);
+    float ssum[MT];  // rows too wide to hold their partials across the weight requests: reduce them now (one or two L2 round trips)
+    if (!sl[0].fast) ssq_rows_now<MT>(a.ssq_in, a.parts, mt0, lane, ssum);
     // 2. every weight chunk of this wave + the epilogue's memory operands
     uint4 A[CPW][NT];
     const uint4* wbase = a.wp + ((size_t)nt0 * a.KCH) * 64 + lane;
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(512) void gemm_normpre_kernel(GemmArgs a) {
     // 3. RMSNorm in registers (gpt.py:143-148), fixed-order statistics
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-        float s = ssq_finish(sl[i], a.ssq_in, a.parts, (mt0 + i) * 16 + (lane & 15), lane);
+        float s = sl[i].fast ? ssq_finish(sl[i]) : ssum[i];
         s += __shfl_xor(s, 16, 64);
         s += __shfl_xor(s, 32, 64);
         const float ri = 1.0f / sqrtf(s * a.inv_k + a.eps);

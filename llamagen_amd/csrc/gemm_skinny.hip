@@ -98,11 +98,11 @@ __global__ __launch_bounds__((gemm_max_threads<MT, NT, NORM, EPI>())) void gemm_
     // 3. RMSNorm row scales from the producer's partial sums of squares (fixed order)
     float ri[MT];
     if constexpr (NORM) {
+        float ssum[MT];
+        ssq_rows_now<MT>(a.ssq_in, a.parts, mt0, lane, ssum);
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-            const int row = (mt0 + i) * 16 + (lane & 15);
-            const SsqLoads<4> sl = ssq_issue<4>(a.ssq_in, a.parts, row, lane);
-            float s = ssq_finish(sl, a.ssq_in, a.parts, row, lane);
+            float s = ssum[i];
             s += __shfl_xor(s, 16, 64);
             s += __shfl_xor(s, 32, 64);
             ri[i] = 1.0f / sqrtf(s * a.inv_k + a.eps);

@@ -250,8 +250,9 @@ class DecodeEngine:
         kch = K // self.kc
         if fused and kch % 8 == 0 and 3 <= kch // 8 <= 6:
             # normpre kernel: every workgroup normalises its own rows of the panel, so halve the rows per
-            # workgroup and group n-tiles instead (measured best at MTs = 4: qkv (1,4,8), w1||w3 (2,4,8))
-            mt = max(1, self.mt // (4 if kind == "qkv" else 2))
+            # workgroup and group n-tiles instead (measured best at MTs = 4: qkv (1,4,8), w1||w3 (2,4,8); at MTs = 8, i.e. two
+            # reference batches per chain, qkv (2,4,8): +18 % decode throughput of one 128-row chain, tools/exp_r2e.py)
+            mt = max(1, self.mt // (4 if kind == "qkv" and self.MTs <= 4 else 2))
             nt = 4
             while ntiles % nt or (kind == "w13" and nt & 1 and nt > 1):
                 nt //= 2

@@ -107,8 +107,18 @@ class SamplingPipeline:
     results are enqueued-behind on the CURRENT stream when run() returns (no host synchronisation)."""
 
     def __init__(self, gpt, vq=None, lanes: int = 2, steps_per_turn: int = 1, vq_low_priority: bool = False,
-                 cu_partition: Optional[bool] = None, vq_cus: int = 0, lanes_avoid_vq_cus: bool = False):
+                 cu_partition: Optional[bool] = None, vq_cus: int = 0, lanes_avoid_vq_cus: bool = False,
+                 batches_per_chain: int = 1):
         self.dev = next(gpt.parameters()).device
+        # `batches_per_chain` consecutive batches of run() share ONE decode chain (their rows are concatenated): rows never
+        # interact before the sampler and the sampler pairs row b with row B + b only, so every image is what its own
+        # generate() call would have produced from the same noise, while the chain's fixed costs (a dependent launch per
+        # kernel, the weight stream of every GEMM) are paid once for twice the rows.  Measured on MI355X, GPT-L 384 px,
+        # 32 images per batch: one chain in flight 47 -> 61-70 img/s, 3 chains in flight 76 -> 85+ (tools/exp_r2e.py).
+        self.bpc = max(1, int(batches_per_chain))
+        if self.bpc > 1 and gpt.model_type != "c2i":
+            raise NotImplementedError("batches_per_chain > 1 is built for class-conditional models (per-batch caption masks "
+                                      "would have to be concatenated too)")
         # optional: one shared stream for every lane's VQ decode (see SamplingLane)
         self.vq_stream = torch.cuda.Stream(device=self.dev, priority=0) if (vq is not None and vq_low_priority) else None
         # experiment (bench.py --vq-cus N): the MFMA-bound decoder kernels fill the register file of every CU they run on
@@ -148,7 +158,7 @@ class SamplingPipeline:
         conds = []
         for _ in self.lanes:
             if gpt.model_type == "c2i":
-                conds.append(torch.randint(0, max(1, gpt.num_classes), (batch,), generator=g).to(self.dev))
+                conds += [torch.randint(0, max(1, gpt.num_classes), (batch,), generator=g).to(self.dev) for _ in range(self.bpc)]
             else:
                 conds.append(torch.zeros(batch, gpt.cls_token_num, gpt.config.caption_dim, device=self.dev,
                                          dtype=gpt.tok_embeddings.weight.dtype))
@@ -168,20 +178,30 @@ class SamplingPipeline:
                 if not lane.busy and nxt < len(conds):
                     # a callable is evaluated only now, so that a driver can draw its labels from the device generator in the
                     # reference's order (labels of batch i, noise of batch i, labels of batch i+1, ...: sample_c2i_ddp.py:128-140)
-                    cond = conds[nxt]() if callable(conds[nxt]) else conds[nxt]
-                    lane.start(nxt, cond, max_new_tokens, decode_shape, gen_kw)
-                    nxt += 1
+                    group = [c() if callable(c) else c for c in conds[nxt:nxt + self.bpc]]
+                    rows = group[0].shape[0]
+                    if any(c.shape[0] != rows for c in group):
+                        raise ValueError("batches that share a chain must have the same size")
+                    # a last, incomplete group repeats its last batch (rows computed and dropped): one chain shape per lane
+                    chain = group[0] if self.bpc == 1 else torch.cat(group + [group[-1]] * (self.bpc - len(group)))
+                    shape = None if decode_shape is None else [chain.shape[0]] + list(decode_shape[1:])
+                    lane.start((nxt, len(group), rows), chain, max_new_tokens, shape, gen_kw)
+                    nxt += len(group)
             active = [lane for lane in self.lanes if lane.busy]
             if not active:
                 break
             for lane in active:
                 done = lane.advance(self.steps_per_turn)
                 if done is not None:
-                    if on_done is not None:
-                        with torch.cuda.stream(lane.vq_stream), torch.no_grad():
-                            results[done[0]] = on_done(*done)
-                    else:
-                        results[done[0]] = (done[1], done[2])
+                    (first, n, rows), ids, img = done
+                    for i in range(n):  # hand the chain's batches back one by one, in submission order
+                        sl = slice(i * rows, (i + 1) * rows)
+                        part = (first + i, ids[sl], None if img is None else img[sl])
+                        if on_done is not None:
+                            with torch.cuda.stream(lane.vq_stream), torch.no_grad():
+                                results[first + i] = on_done(*part)
+                        else:
+                            results[first + i] = (part[1], part[2])
         cur = torch.cuda.current_stream(self.dev)
         for lane in self.lanes:
             cur.wait_stream(lane.stream)

@@ -157,7 +157,7 @@ def test_hot_kernels_have_no_register_spills():
             if m and cur is not None:
                 cur[m.group(1).strip()] = int(m.group(2))
     assert len(kernels) > 100
-    allowed = [r"gemm_kernelI(4BF16|3F16)Li8ELi[12]ELi\dELb1ELi2E",  # ring-buffer NORM GEMM at mt = 8 (engine uses mt <= 4)
+    allowed = [r"gemm_kernelI(4BF16|3F16|3F32)Li8ELi[12]ELi\dELb1ELi2E",  # ring-buffer NORM GEMM at mt = 8 (engine uses mt <= 4)
                r"gemm_kernelI(4BF16|3F16)Li4ELi4ELi5ELb1ELi2E",     # ring-buffer NORM qkv at (4, 4): fused qkv runs (1, 4) / (2, 4)
                r"rmsnorm_kernelI(4BF16|3F16)Li16E",                 # 16-bit rows wider than 4096 (no registry model)
                r"igemm_kernelILi4ELi4ELi2ELi1E"]                 # conv variant 1 (double-staged both operands), not the default

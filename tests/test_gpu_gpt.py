@@ -526,6 +526,50 @@ def test_pipeline_lanes_match_sequential_generate():
             assert torch.equal(rimg, oimg), lanes
 
 
+def test_pipeline_batches_per_chain_rows_are_independent():
+    """SamplingPipeline(batches_per_chain=2): two batches share one decode chain (rows concatenated, CFG pairs row b with
+    row 2B + b).  Each batch must come out exactly as its own generate() + decode_code() call does from the same Exp(1)
+    draws (fp32: token for token); an incomplete last chain is padded and the padding dropped."""
+    from llamagen_amd import VQ_models, generate
+    from llamagen_amd.gpt import ModelArgs, Transformer
+    from llamagen_amd.pipeline import SamplingPipeline
+    from llamagen_amd.testing import synth_for_module
+    dev = _dev()
+    kw = dict(n_layer=2, n_head=4, dim=256, vocab_size=1024, block_size=16, num_classes=10, cls_token_num=1, model_type="c2i")
+    m = Transformer(ModelArgs(**kw))
+    m.load_state_dict(synth_for_module(m, seed=1, lin_std=0.05), strict=False)
+    m = m.to(device=dev).eval()
+    vq = VQ_models["VQ-16"](codebook_size=1024, codebook_embed_dim=8)
+    vq.load_state_dict(synth_for_module(vq, seed=3))
+    vq = vq.to(dev).eval()
+    skw = dict(cfg_scale=4.0, cfg_interval=-1, temperature=1.0, top_k=100, top_p=1.0, sample_logits=True)
+    B, N = 3, 16
+    conds = [torch.randint(0, 10, (B,), generator=torch.Generator().manual_seed(i)).to(dev) for i in range(3)]
+    noise = torch.empty(N, 2 * B, 1024).exponential_(1.0, generator=torch.Generator().manual_seed(5)).to(dev)
+    ref = []
+    for i in range(2):
+        idx = generate(m, conds[i], N, _noise_seq=noise[:, i * B:(i + 1) * B].contiguous(), **skw)
+        ref.append((idx.clone(), vq.decode_code(idx, [B, 8, 4, 4]).clone()))
+    m._engine = None
+    pipe = SamplingPipeline(m, vq, lanes=1, batches_per_chain=2)
+    out = pipe.run(conds[:2], N, decode_shape=[B, 8, 4, 4], _noise_seq=noise, **skw)
+    torch.cuda.synchronize()
+    assert len(out) == 2
+    for (ri, rimg), (oi, oimg) in zip(ref, out):
+        assert torch.equal(ri, oi)
+        assert (rimg - oimg).abs().max().item() <= 1e-5
+    # three batches on two lanes: chain 0 = batches 0, 1; chain 1 = batch 2 + padding
+    pipe = SamplingPipeline(m, vq, lanes=2, batches_per_chain=2)
+    pipe.prepare(B, N, **skw)
+    seen = []
+    out = pipe.run(conds, N, decode_shape=[B, 8, 4, 4], on_done=lambda j, ids, img: (seen.append(j), ids.clone(), img.clone())[1:], **skw)
+    torch.cuda.synchronize()
+    assert sorted(seen) == [0, 1, 2] and len(out) == 3
+    for ids, img in out:
+        assert tuple(ids.shape) == (B, N) and tuple(img.shape) == (B, 3, 64, 64)
+        assert int(ids.min()) >= 0 and int(ids.max()) < 1024 and bool(torch.isfinite(img).all())
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 def test_t2i_batched_prefill_matches_sequential(dt, monkeypatch):
     """The batched prefix prefill (all T caption positions per layer at once: lgen_rope_append_prefill,

@@ -261,6 +261,8 @@ def main():
     ap.add_argument("--lanes-avoid-vq-cus", action="store_true", help="experiment: with --vq-cus, keep the decode lanes off those CUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-solo", action="store_true", help="skip the extra one-generate()-at-a-time leg (64-row chains; keeps a "
+                                                           "rocprofv3 kernel average of this run to the timed chain shape)")
     args = ap.parse_args()
 
     from llamagen_amd import dist as ldist
@@ -414,7 +416,7 @@ def main():
                                          "ms_per_decode_code": round(vq_ms, 2), "flop_per_image_fp32": 570.1e9, "mfma_passes": 3,
                                          "hipblaslt_bf16_gemm_8192_random_TFLOPs": round(lib_tf, 1),
                                          "frac_of_that_measured_ceiling": round(tf / lib_tf, 4)}
-        if world == 1 and bpc * args.lanes > 1:
+        if world == 1 and bpc * args.lanes > 1 and not args.no_solo:
             # ... and with ONE generate() + decode_code() of 32 images in flight at a time (no cross-batch sharing at all): a fresh
             # single-lane pipeline at 64 rows, set up and timed after everything above
             pipe = None

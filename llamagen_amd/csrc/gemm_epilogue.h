@@ -62,7 +62,7 @@ LGEN_DEV void prefetch_retire(const char* base, unsigned token) {
 // single wait in between (the round-1 form, a runtime-length loop of 4-byte loads, made the compiler wait for every group of
 // four before the weight stream was even requested: 2-3 us per fused-norm GEMM).
 template <int NV>
-struct SsqLoads { float4 v[NV]; int n4; bool fast; };
+struct SsqLoads { float4 v[NV > 0 ? NV : 1]; int n4; bool fast; };
 // NV (16-byte loads a lane keeps in flight per m-tile) shrinks with the m-tiles of a workgroup: 8 / 4 / 2 for MT = 1 / 2 / >= 4,
 // i.e. the no-wait form covers d <= 2048 / 1024 / 512; wider rows are reduced before the weights are requested (ssq_rows_now).
 template <int MT>

@@ -44,10 +44,13 @@ def main():
     if "grid" in which:
         for B, lanes in [(32, 3), (64, 1), (64, 2), (64, 3), (96, 2), (32, 1), (32, 3)]:
             run(gpt, vq, B, lanes, tag="E5")
+    if "wide" in which:
+        for B, lanes in [(128, 1), (128, 2), (64, 3)]:
+            run(gpt, vq, B, lanes, images=512, tag="E7")
     if "tiles" in which:
         # (round 2, after the statistics of wide m-tiles were fixed to one L2 round trip; qkv=2,4,8 is the default at 128 rows)
-        sets = {"default": "", "qkv42": "qkv=4,2,8", "w44": "w13=4,4,8", "h44": "head=4,4,8", "w42": "w13=4,2,8",
-                "q42_w44_h44": "qkv=4,2,8;w13=4,4,8;head=4,4,8", "res4": "wo=4,1,8;w2=4,1,8"}
+        sets = {"default": "", "w22": "w13=2,2,8", "h22": "head=2,2,8", "q22": "qkv=2,2,8", "q14": "qkv=1,4,8", "w14": "w13=1,4,8",
+                "w22_q22": "w13=2,2,8;qkv=2,2,8"}
         for name, spec in sets.items():
             os.environ["LGEN_TILES"] = spec
             try:

@@ -4,7 +4,8 @@ readable profiles/r02_pmc.csv.  FETCH_SIZE is in KB and counts HALF of a wide co
 import csv, glob, json, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-d, H, hd, F, V, B2 = 1024, 16, 64, 2816, 16384, 64
+d, H, hd, F, V = 1024, 16, 64, 2816, 16384
+B2 = 2 * int(os.environ.get("LGEN_PMC_B", "64"))  # rows of the decode chain (tools/pmc_target.py)
 GEMM = {  # kernel-name fragment -> (bench key, algorithmic weight bytes)
     "EPI_QKV": ("wqkv", 3 * d * d * 2), "5, 4>(GemmArgs)": ("wqkv", 3 * d * d * 2),
 }
@@ -18,7 +19,7 @@ def rows(pattern):
 
 
 def classify(name, grid):
-    """decode-chain kernel -> (key, algorithmic bytes read) for GPT-L, M = 64."""
+    """decode-chain kernel -> (key, algorithmic bytes read) for GPT-L."""
     if "attn_decode_kernel" in name:
         return "attn", None
     if "gemm_normpre_kernel" in name or "gemm_kernel" in name:
@@ -42,6 +43,7 @@ def main(fetch_dir, write_dir):
     for counter, ddir, scale in (("FETCH_SIZE", fetch_dir, 2048.0), ("WRITE_SIZE", write_dir, 1024.0)):
         acc = {}
         attn_seq = []
+        res_seq = []
         for r in rows(os.path.join(ddir, "**", "*counter_collection.csv")):
             if r["Counter_Name"] != counter:
                 continue
@@ -52,8 +54,15 @@ def main(fetch_dir, write_dir):
             if key == "attn":
                 attn_seq.append((int(r["Dispatch_Id"]), val))
                 continue
-            if key == "res":  # wo: N = d -> grid 64 n-tiles x ...; tell apart by the K split is not visible: use fetched bytes
-                key, alg = ("wo", d * d * 2) if val < 0.6 * (F * d * 2) else ("w2", F * d * 2)
+            if key == "res":  # wo and w2 share instantiation and grid (N = d for both): they alternate in dispatch order
+                res_seq.append((int(r["Dispatch_Id"]), val))
+                continue
+            a = acc.setdefault(key, [0, 0.0, alg])
+            a[0] += 1
+            a[1] += val
+        res_seq.sort()
+        for i, (_, val) in enumerate(res_seq):  # per layer: ... attention, wo (RES), w1||w3, w2 (RES) ...
+            key, alg = ("wo", d * d * 2) if i % 2 == 0 else ("w2", F * d * 2)
             a = acc.setdefault(key, [0, 0.0, alg])
             a[0] += 1
             a[1] += val
@@ -81,10 +90,11 @@ def main(fetch_dir, write_dir):
             else:
                 res.setdefault("attn_decode_kernel", {})["write_bytes_per_launch"] = int(sum(last) / 72)
     res.setdefault("attn_decode_kernel", {})["source"] = res["gemm"]["source"]
+    res["rows"] = B2
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     json.dump(res, open(os.path.join(ROOT, "profiles", "r02_pmc.json"), "w"), indent=1)
     with open(os.path.join(ROOT, "profiles", "r02_pmc.csv"), "w") as f:
-        f.write("# rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separate pass, WRITE_SIZE) -- python tools/pmc_target.py ; GPT-L bf16, B2 = 64\n")
+        f.write(f"# rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separate pass, WRITE_SIZE) -- python tools/pmc_target.py ; GPT-L bf16, B2 = {B2}\n")
         f.write("# FETCH_SIZE KB x 1024 x 2 (gfx950 correction for wide coalesced reads, MI355X_MICROARCH.md); WRITE_SIZE KB x 1024\n")
         f.write("counter,kernel,launches,bytes_per_launch,algorithmic_bytes,ratio\n")
         for t in table:

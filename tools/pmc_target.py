@@ -1,6 +1,7 @@
 """Workload for the PMC passes of the round (run under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and, in a SEPARATE
-pass, `--pmc WRITE_SIZE`): (1) a short GPT-L bf16 B=32 cfg-4 generate() (the decode-chain GEMM kernels with the bench's
-tile shapes; 40 tokens keep the serialized, counter-instrumented run short), (2) the decode attention at cache positions
+pass, `--pmc WRITE_SIZE`): (1) a short GPT-L bf16 cfg-4 generate() of LGEN_PMC_B images (default 64 = the bench's two batches
+per chain, 128 rows; the decode-chain GEMM kernels with the bench's tile shapes; 40 tokens keep the serialized,
+counter-instrumented run short), (2) the decode attention at cache positions
 63 / 287 / 575 on full-size KV slabs, one launch per layer.  tools/pmc_summary.py turns the two outputs into
 profiles/r02_pmc.json, which bench.py quotes as `traffic`."""
 import os, sys
@@ -10,7 +11,7 @@ from llamagen_amd import GPT_models, generate
 from llamagen_amd import _lib as L
 
 dev = torch.device("cuda:0")
-N, B = 576, 32
+N, B = 576, int(os.environ.get("LGEN_PMC_B", "64"))
 torch.manual_seed(0)
 m = GPT_models["GPT-L"](vocab_size=16384, block_size=N, num_classes=1000, cls_token_num=1, model_type="c2i")
 torch.nn.init.normal_(m.output.weight, 0, 0.02)

@@ -1,10 +1,11 @@
-"""Parity of the kernels `bench.py` actually times (BASELINE config 2: GPT-L bf16, B2 = 64, fused-norm tiles,
-32 x 24 x 24 decode_code) and of the config 3-5 kernel shapes against the CPU oracle.
+"""Parity of the kernels `bench.py` actually times (BASELINE config 2: GPT-L bf16, fused-norm tiles, 32 x 24 x 24
+decode_code; 64 rows = one batch per chain, 128 rows = the default two batches per chain) and of the config 3-5 kernel
+shapes against the CPU oracle.
 
 The small-model tests of test_gpu_gpt.py pin the arithmetic; these pin the *instantiations*: the
-`gemm_normpre_kernel<BF16, 1, 4, EPI_QKV, 4>`, `<2, 4, EPI_SWIGLU, 4>`, `<2, 4, EPI_ROWS, 4>`,
-`gemm_kernel<BF16, 1, 1, EPI_RES, false, 6>` and `attn_decode_kernel<BF16, 8, 2, 2>` forms that the
-headline run replays, at late cache positions too.
+`gemm_normpre_kernel<BF16, 1, 4, EPI_QKV, 4>` (64 rows) / `<2, 4, EPI_QKV, 4>` (128 rows), `<2, 4, EPI_SWIGLU, 4>`,
+`<2, 4, EPI_ROWS, 4>`, `gemm_kernel<BF16, 1, 1, EPI_RES, false, 6>` / `<2, 1, EPI_RES, false, 6>` and
+`attn_decode_kernel<BF16, 8, 2, 2>` forms that the headline run replays, at late cache positions too.
 
 Tolerance (bf16 storage, stated here as the prompt asks): CFG-mixed logits within 4 (max) / 0.25 (mean)
 bf16 ulp of the largest logit -- the bar of test_forward_teacher_forced_bf16.  A bf16 model is not
@@ -161,18 +162,34 @@ def test_config2_gptl_bf16_b64_logits_vs_oracle():
     _check("config2_gptl_b64", recs)
 
 
-@pytest.mark.parametrize("d,H", [(1024, 16), (1280, 20), (1536, 24), (768, 12)])
+def test_config2_gptl_bf16_two_batches_per_chain_logits_vs_oracle():
+    """bench.py's default schedule: two batches of 32 share one decode chain -> 128 rows, MTs = 8, qkv tile (2, 4, 8), RES GEMMs at
+    mt = 2: prefill, positions 1..3 and position 299 on injected cache contents, same bar as the 64-row test."""
+    case = dict(registry="GPT-L", kwargs=dict(vocab_size=16384, block_size=576, num_classes=1000, cls_token_num=1,
+                                              model_type="c2i"), wseed=21, lin_std=0.02)
+    B = 64
+    cond = torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(4))
+    recs, m = _teacher_forced(case, B, 4.0, early=3, late=[299], cond=cond)
+    e = m._engine
+    assert e.fuse_norm and e.MTs == 8 and e.S8 == 584
+    assert e._tiles("qkv", 3 * e.d, e.d) == (2, 4, 8) and e._tiles("w13", 2 * e.F, e.d) == (2, 4, 8)  # what bench.py replays
+    _check("config2_gptl_b128", recs)
+
+
+@pytest.mark.parametrize("d,H,M,mt", [(1024, 16, 64, 1), (1280, 20, 64, 1), (1536, 24, 64, 1), (768, 12, 64, 1),
+                                      (1024, 16, 128, 2), (1536, 24, 128, 2)])
 @pytest.mark.parametrize("pos", [0, 301])
-def test_qkv_fused_norm_rope_append_vs_oracle(d, H, pos):
-    """lgen_gemm_qkv_rope WITH the fused RMSNorm (norm_w / ssq_in), 64 rows, tiles (1, 4, 8): CPW 3 / 4 / 5 / 6 =
-    GPT-B / L / XL / XXL, vs oracle rms_norm -> linear -> apply_rotary_emb -> KVCache.update."""
+def test_qkv_fused_norm_rope_append_vs_oracle(d, H, M, mt, pos):
+    """lgen_gemm_qkv_rope WITH the fused RMSNorm (norm_w / ssq_in): 64 rows with tiles (1, 4, 8) and 128 rows (two batches per
+    chain, bench.py's default) with tiles (2, 4, 8); CPW 3 / 4 / 5 / 6 = GPT-B / L / XL / XXL, vs oracle rms_norm -> linear ->
+    apply_rotary_emb -> KVCache.update."""
     from llamagen_amd.engine import pack_act, pack_weight, precompute_freqs_cis_2d
     from tests.test_gpu_gpt import _close, _rand
     L, dev = _L(), _dev()
     lib = L.lib()
-    dt, M, hd, grid = torch.bfloat16, 64, 64, 24
+    dt, hd, grid = torch.bfloat16, 64, 24
     S8 = O.find_multiple(1 + grid * grid, 8)
-    mts = 4
+    mts = M // 16
     x = _rand((M, d), dt, 41, 1.3)
     w = _rand((3 * d, d), dt, 42, 0.03)
     nw = (1 + 0.1 * _rand((d,), torch.float32, 43)).to(dt)
@@ -185,7 +202,7 @@ def test_qkv_fused_norm_rope_append_vs_oracle(d, H, pos):
     q = torch.zeros(mts * 16, H, 64, dtype=dt, device=dev)
     state = torch.tensor([pos, 0], dtype=torch.int32, device=dev)
     L.check(lib.lgen_gemm_qkv_rope(L.ptr(wp), L.ptr(xp), L.ptr(q), L.ptr(kc), L.ptr(vc), L.ptr(fr_d), L.ptr(state), M, mts, d, H,
-                                   hd, 64, S8, 0, L.BF16, 1, 4, 8, L.ptr(nw_d), L.ptr(ssq), d // 16, 1e-5, L.stream()), "qkv fused")
+                                   hd, 64, S8, 0, L.BF16, mt, 4, 8, L.ptr(nw_d), L.ptr(ssq), d // 16, 1e-5, L.stream()), "qkv fused")
     xn = O.rms_norm(x.float(), nw, 1e-5, dt)
     qkv = O.linear(xn, w.float(), dt)
     xq, xk, xv = qkv.split([d, d, d], dim=-1)

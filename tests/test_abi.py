@@ -184,3 +184,10 @@ def test_lane_cu_masks_partition_the_chip():
                     assert acc & m[w] == 0
                     acc |= m[w]
             assert all(0 <= w < 2 ** 32 for m in masks for w in m)
+
+
+def test_graft_entry_build_passes():
+    """The driver's build check (__graft_entry__.build): make is a no-op on an up-to-date tree, every symbol binds, the ABI
+    version of the library is the one llamagen_amd._lib expects."""
+    import __graft_entry__ as g
+    g.build()

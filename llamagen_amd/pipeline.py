@@ -202,9 +202,13 @@ class SamplingPipeline:
                                 results[first + i] = on_done(*part)
                         else:
                             results[first + i] = (part[1], part[2])
+        self._join()
+        return results
+
+    def _join(self):
+        """The caller's stream waits for every lane: results are enqueued-behind when run() returns."""
         cur = torch.cuda.current_stream(self.dev)
         for lane in self.lanes:
             cur.wait_stream(lane.stream)
         if self.vq_stream is not None:
             cur.wait_stream(self.vq_stream)
-        return results

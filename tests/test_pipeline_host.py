@@ -1,0 +1,84 @@
+"""Host logic of llamagen_amd.pipeline.SamplingPipeline.run (no GPU): which batches share a decode chain, the padding of an
+incomplete last chain, the per-batch hand-back (on_done once per batch, in the reference's batch order) and lane refill.
+The lanes are stand-ins that "generate" ids = label * 1000 + token position, so every output row names the input row it
+came from."""
+import torch
+
+from llamagen_amd.pipeline import SamplingPipeline
+
+
+class _Lane:
+    def __init__(self, steps):
+        self.stream = self.vq_stream = None
+        self.steps, self.left, self.job, self.started = steps, 0, None, []
+
+    @property
+    def busy(self):
+        return self.job is not None
+
+    def start(self, job_id, cond, max_new_tokens, decode_shape, gen_kw):
+        self.job, self.left = (job_id, cond.clone(), max_new_tokens, decode_shape), self.steps
+        self.started.append((job_id, cond.clone(), decode_shape))
+
+    def advance(self, nsteps=1):
+        self.left -= nsteps
+        if self.left > 0:
+            return None
+        job_id, cond, N, shape = self.job
+        self.job = None
+        ids = cond[:, None] * 1000 + torch.arange(N)[None]
+        img = ids[:, :1].float().reshape(-1, 1, 1, 1).expand(-1, 3, 2, 2)
+        return job_id, ids, img
+
+
+class _Pipe(SamplingPipeline):
+    def __init__(self, lanes, bpc):  # the real constructor creates HIP streams and decode engines
+        self.dev, self.lanes, self.steps_per_turn, self.vq_stream, self.bpc = torch.device("cpu"), lanes, 1, None, bpc
+
+    def _join(self):
+        pass
+
+
+def _conds(k, rows=3):
+    return [torch.arange(rows) + 10 * i for i in range(k)]
+
+
+def test_one_batch_per_chain_keeps_submission_order():
+    lanes = [_Lane(4), _Lane(2)]
+    out = _Pipe(lanes, 1).run(_conds(5), 6)
+    assert [int(ids[0, 0]) // 1000 for ids, _ in out] == [0, 10, 20, 30, 40]
+    assert [j[0][0] for lane in lanes for j in lane.started] != []  # both lanes took work
+    assert sorted(j[0][0] for lane in lanes for j in lane.started) == [0, 1, 2, 3, 4]
+    for ids, img in out:
+        assert tuple(ids.shape) == (3, 6) and tuple(img.shape) == (3, 3, 2, 2)
+
+
+def test_two_batches_per_chain_group_pad_and_split():
+    lanes = [_Lane(3), _Lane(3)]
+    seen = []
+    conds = _conds(5)
+    out = _Pipe(lanes, 2).run(conds, 4, decode_shape=[3, 8, 2, 2], on_done=lambda j, ids, img: (seen.append(j), ids, img)[1:])
+    chains = sorted((j for lane in lanes for j in lane.started), key=lambda t: t[0][0])
+    assert [(c[0][0], c[0][1]) for c in chains] == [(0, 2), (2, 2), (4, 1)]  # (first batch, batches in the chain)
+    for (first, n, rows), cond, shape in chains:
+        assert rows == 3 and cond.shape[0] == 6 and shape == [6, 8, 2, 2]  # every chain has the full chain shape
+        want = torch.cat([conds[first + i] for i in range(n)] + [conds[first + n - 1]] * (2 - n))
+        assert torch.equal(cond, want)  # an incomplete chain repeats its last batch
+    assert sorted(seen) == [0, 1, 2, 3, 4] and len(out) == 5  # on_done once per BATCH; the padding is dropped
+    for i, (ids, img) in enumerate(out):
+        assert torch.equal(ids[:, 0] // 1000, conds[i]) and tuple(ids.shape) == (3, 4) and tuple(img.shape) == (3, 3, 2, 2)
+
+
+def test_callable_conds_are_drawn_in_batch_order_and_sizes_must_match():
+    order = []
+
+    def mk(i):
+        return lambda: (order.append(i), torch.arange(2) + 10 * i)[1]
+    out = _Pipe([_Lane(1), _Lane(1)], 2).run([mk(i) for i in range(4)], 3)
+    assert order == [0, 1, 2, 3] and [int(ids[0, 0]) // 1000 for ids, _ in out] == [0, 10, 20, 30]
+    try:
+        _Pipe([_Lane(1)], 2).run([torch.arange(2), torch.arange(3)], 3)
+    except ValueError:
+        pass
+    else:
+        raise AssertionError("batches of different sizes must not share a chain")

@@ -42,8 +42,6 @@ SIGNATURES = {
     "lgen_set_conv_fused_variant": [_I],
     "lgen_stream_create_cu_mask": [_P, _I, _P],
     "lgen_stream_destroy": [_P],
-    "lgen_set_weight_nt": [_I],
-    "lgen_set_kv_nt": [_I],
     "lgen_set_vq_nt": [_I],
     "lgen_attn_decode": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "lgen_rope_append_prefill": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],

@@ -25,11 +25,12 @@ struct GemmArgs {
     float eps, inv_k;
     const char* pf;      // weights of the NEXT kernel of the chain (nullable): pulled towards the memory-side cache
     long long pf_bytes;
-    int nt;              // weight loads non-temporal (streamed once) or default cache policy (shared between lanes)
 };
-// weight chunk load with the policy of this launch (uniform branch)
-LGEN_DEV uint4 ldg_w(const uint4* p, int nt) { return nt ? ldg_nt(p) : *p; }
-int lgen_weight_nt();  // gemm_skinny.hip
+// weight chunk load: default cache policy (chains in flight share the weights through the memory-side cache; measured better than
+// non-temporal).  One plain load, NOT a run-time choice of policy: a branch per load makes the compiler lose count of the loads in
+// flight and wait for all of them (s_waitcnt vmcnt(0)) in front of the first MFMA, which turns the operand ring into load-all /
+// wait-all / compute-all (round 2, found in the ISA of gemm_kernel<BF16,2,1,EPI_RES,false,6>).
+LGEN_DEV uint4 ldg_w(const uint4* p) { return *p; }
 
 // Fire-and-forget reads of the next kernel's weight matrix, one dword per 64-byte line, issued BEFORE this
 // wave's own operand loads.  Each kernel of the decode chain is latency-bound and starts with a cold weight

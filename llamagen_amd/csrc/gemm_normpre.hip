@@ -53,7 +53,7 @@ __global__ __launch_bounds__(512) void gemm_normpre_kernel(GemmArgs a) {
 #pragma unroll
     for (int c = 0; c < CPW; ++c)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) A[c][j] = ldg_w(wbase + j * wstride + (size_t)(k0 + c) * 64, a.nt);
+        for (int j = 0; j < NT; ++j) A[c][j] = ldg_w(wbase + j * wstride + (size_t)(k0 + c) * 64);
     uint4 aux[UNITS];
 #pragma unroll
     for (int q = 0; q < UNITS; ++q) aux[q] = make_uint4(0, 0, 0, 0);

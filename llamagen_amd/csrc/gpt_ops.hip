@@ -249,7 +249,6 @@ struct AttnArgs {
     int H, hd, hdp, S8, MTs;
     float sf;            // sqrt(1/sqrt(hd))
     int kvs;             // elements between consecutive cache rows (hdp, or 2*hdp for an interleaved K|V slab)
-    int nt;              // K/V loads non-temporal (each row is read once per step; keeps the weights cached)
     int mask_len;        // only keys < mask_len consult the mask row (t2i: the caption prefix); the rest is pure causal
     const char* pf;      // next kernel's weights (wo), see prefetch_lines in gemm_epilogue.h
     long long pf_bytes;
@@ -280,8 +279,8 @@ __global__ __launch_bounds__(64 * ATT_NW, (ATT_CH <= 2 ? 4 : 2)) void attn_decod
         _Pragma("unroll") for (int j = 0; j < ATT_CH; ++j) {                \
             int kk = (g) * GK + j * KPL + kin;                              \
             kk = kk < smax ? kk : smax;                                     \
-            KB[j] = a.nt ? ldg_nt(kp + (size_t)kk * rpr) : kp[(size_t)kk * rpr]; \
-            VB[j] = a.nt ? ldg_nt(vp + (size_t)kk * rpr) : vp[(size_t)kk * rpr]; \
+            KB[j] = ldg_nt(kp + (size_t)kk * rpr);                          \
+            VB[j] = ldg_nt(vp + (size_t)kk * rpr);                          \
         }                                                                   \
     }
     // group g of this wave: g = wv, wv + NW, ...; first group requested before pos is known
@@ -376,17 +375,16 @@ __global__ __launch_bounds__(64 * ATT_NW, (ATT_CH <= 2 ? 4 : 2)) void attn_decod
 // every workgroup of a B2 x H = 1024 grid resident at once, lowest fixed cost (4.4 us at kv_len 1 vs 6.1 us with
 // 4 waves) and the same 6.4 TB/s incremental rate at long kv_len; 1 = (2, 4); 0 = (4, 4); 3 = (4, 2); 4 = (2, 1); 5 = (4, 1)
 static int g_attn_variant = 2;
-// non-temporal K/V loads: every cache row is read once per step, and keeping 75-150 MB per layer out of the
-// memory-side cache leaves the (lane-shared) weights there: 26.5 vs 28.5 us at kv_len 576, 71.6 vs 68.6 img/s
-static int g_kv_nt = 1;
-extern "C" int lgen_set_kv_nt(int v) { g_kv_nt = v ? 1 : 0; return 0; }
+// K/V loads are non-temporal (ldg_nt in ATT_LOAD): every cache row is read once per step, and keeping 75-150 MB per layer out
+// of the memory-side cache leaves the (chain-shared) weights there: 26.5 vs 28.5 us at kv_len 576, 71.6 vs 68.6 img/s.  Fixed
+// at compile time: a per-load run-time choice costs the compiler its count of loads in flight (vmcnt(0) before every compute).
 extern "C" int lgen_set_attn_variant(int v) { g_attn_variant = v; return 0; }
 
 static int attn_decode_impl(const void* q, const void* k_cache, const void* v_cache, void* out_packed,
                             const int* pos_ptr, int pos_stride, const unsigned char* mask, int mask_len, int B2, int MTs,
                             int n_head, int hd, int hdp, int S8, int kv_row_stride, int dtype, void* stream) {
     AttnArgs a{q, k_cache, v_cache, out_packed, pos_ptr, pos_stride, mask, n_head, hd, hdp, S8, MTs, 0.f,
-               kv_row_stride > 0 ? kv_row_stride : hdp, g_kv_nt, mask_len > 0 ? mask_len : S8, nullptr, 0};
+               kv_row_stride > 0 ? kv_row_stride : hdp, mask_len > 0 ? mask_len : S8, nullptr, 0};
     lgen_take_prefetch_hint(&a.pf, &a.pf_bytes);
     a.sf = sqrtf(1.0f / sqrtf((float)hd));
     hipStream_t st = (hipStream_t)stream;

@@ -99,10 +99,6 @@ class DecodeEngine:
         if dtype not in (torch.bfloat16, torch.float32, torch.float16):
             raise NotImplementedError(f"the HIP engine implements --precision bf16, fp16 and none (fp32), not {dtype}")
         self.lib = L.lib()
-        if os.environ.get("LGEN_WEIGHT_NT") is not None:  # tuning knob, see lgen_set_weight_nt in lgen.h
-            self.lib.lgen_set_weight_nt(int(os.environ["LGEN_WEIGHT_NT"]))
-        if os.environ.get("LGEN_KV_NT") is not None:
-            self.lib.lgen_set_kv_nt(int(os.environ["LGEN_KV_NT"]))
         if os.environ.get("LGEN_ATTN_VARIANT") is not None:  # tuning knob, see lgen_set_attn_variant in lgen.h
             self.lib.lgen_set_attn_variant(int(os.environ["LGEN_ATTN_VARIANT"]))
         self.dev = model.tok_embeddings.weight.device

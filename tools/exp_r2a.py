@@ -51,8 +51,7 @@ def e1(gpt):
         for t in (e.k_cache[i], e.v_cache[i]):
             L.check(lib.lgen_touch_lines(L.ptr(t), (pos + 1) * e.hdp * 2, row_stride, rows, 0, 0, blocks, L.stream()), "touch")
 
-    for nt in (1, 0):
-        lib.lgen_set_kv_nt(nt)
+    for nt in (1,):  # (the K/V cache policy was a run-time knob when this ran; it is fixed to non-temporal now)
         for pos in (64, 144, 288, 575):
             e.state.copy_(torch.tensor([pos, pos], dtype=torch.int32, device=dev))
             res = {}
@@ -78,7 +77,6 @@ def e1(gpt):
             mb = (pos + 1) * 2 * e.H * e.hd * 2 * e.B2 / 1e6
             print(f"E1 kv_nt={nt} pos={pos:3d} ({mb:6.1f} MB): attn plain {res['plain']:6.2f} us  after touch {res['touched']:6.2f} us  "
                   f"(touch K+V itself {res['touch_us']:6.2f} us = {mb / res['touch_us'] * 1e3 / 1e3:.2f} TB/s)", flush=True)
-    lib.lgen_set_kv_nt(1)
 
     # E1b: touch stream next to a GEMM chain
     pos = 288

@@ -23,6 +23,14 @@ def generate(model, cond, max_new_tokens, emb_masks=None, cfg_scale=1.0, cfg_int
             return stop.value
 
 
+def _null_condition(model, cond):
+    """The unconditional twin of every row of `cond` (reference generate.py:128-141): class-conditional models reserve class id
+    `num_classes` for "no class"; text-conditional models carry a learned [T, C] null caption."""
+    if model.model_type == "c2i":
+        return torch.full_like(cond, model.num_classes)
+    return model.cls_embedding.uncond_embedding.to(cond.dtype).expand_as(cond)
+
+
 def generate_iter(model, cond, max_new_tokens, emb_masks=None, cfg_scale=1.0, cfg_interval=-1, **sampling_kwargs):
     """Same arguments as generate(); a generator that yields after every enqueued decode step and returns
     the int32 [B, N] ids (StopIteration.value).  Call it (and every next()) with the lane's stream current
@@ -35,38 +43,24 @@ def generate_iter(model, cond, max_new_tokens, emb_masks=None, cfg_scale=1.0, cf
     if sampling_kwargs:
         raise TypeError(f"unexpected sampling arguments: {sorted(sampling_kwargs)}")
 
-    if model.model_type == "c2i":
-        if cfg_scale > 1.0:
-            cond_null = torch.ones_like(cond) * model.num_classes
-            cond_combined = torch.cat([cond, cond_null])
-        else:
-            cond_combined = cond
-        T = 1
-    elif model.model_type == "t2i":
-        if cfg_scale > 1.0:
-            cond_null = torch.zeros_like(cond) + model.cls_embedding.uncond_embedding.to(cond.dtype)
-            cond_combined = torch.cat([cond, cond_null])
-        else:
-            cond_combined = cond
-        T = cond.shape[1]
-    else:
+    kind = model.model_type
+    if kind not in ("c2i", "t2i"):
         raise Exception("please check model type")
-
-    T_new = T + max_new_tokens
-    max_batch_size = cond.shape[0]
-    max_batch_size_cfg = max_batch_size * 2 if cfg_scale > 1.0 else max_batch_size
-    model.setup_caches(max_batch_size=max_batch_size_cfg, max_seq_length=T_new,
+    use_cfg = cfg_scale > 1.0
+    B = cond.shape[0]
+    prefix = 1 if kind == "c2i" else cond.shape[1]          # conditioning positions in front of the image tokens
+    rows = torch.cat([cond, _null_condition(model, cond)]) if use_cfg else cond   # CFG: conditional rows, then their twins
+    model.setup_caches(max_batch_size=rows.shape[0], max_seq_length=prefix + max_new_tokens,
                        dtype=model.tok_embeddings.weight.dtype)
-
     masks = None
-    if emb_masks is not None:
-        assert emb_masks.shape[0] == max_batch_size
-        assert emb_masks.shape[-1] == T
-        masks = torch.cat([emb_masks, emb_masks]) if cfg_scale > 1.0 else emb_masks
+    if emb_masks is not None:  # [B, T] validity of the (left-padded) caption tokens; the twins see the same pattern
+        assert emb_masks.shape[0] == B
+        assert emb_masks.shape[-1] == prefix
+        masks = emb_masks.repeat(2, *([1] * (emb_masks.dim() - 1))) if use_cfg else emb_masks
 
-    sp = dict(use_cfg=cfg_scale > 1.0, cfg_scale=float(cfg_scale), cfg_interval=int(cfg_interval),
+    sp = dict(use_cfg=use_cfg, cfg_scale=float(cfg_scale), cfg_interval=int(cfg_interval),
               temperature=float(temperature), top_k=int(top_k), top_p=float(top_p),
               sample_logits=bool(sample_logits))
     if noise_seq is not None:
         sp["_noise_seq"] = noise_seq
-    return (yield from model._engine.generate_iter(model, cond_combined, max_batch_size, max_new_tokens, masks, sp))
+    return (yield from model._engine.generate_iter(model, rows, B, max_new_tokens, masks, sp))

@@ -334,6 +334,11 @@ class DecodeEngine:
             hint(self.layers[0]["wqkv"])  # the next decode step starts there
             self.gemm(self.out_w, x_in, self.logits, M, mts, self.V, d, L.EPI_ROWS, th, norm_w=nw)
 
+    def launches_per_step(self) -> int:
+        """Kernel launches of one captured decode step (embed + L layers + norm/lm_head + sampler)."""
+        per_layer = 5 if self.fuse_norm else 7
+        return 1 + len(self.layers) * per_layer + (1 if self.fuse_norm else 2) + 1
+
     def _mask(self):
         if self._force_causal:
             return None

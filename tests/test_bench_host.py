@@ -1,5 +1,9 @@
 """bench.py's accounting helpers (no GPU): the algorithmic bytes behind `roofline.achieved` against SURVEY.md section 8d's
 closed form, and the JSON contract's static fields."""
+import json
+import os
+import subprocess
+import sys
 import types
 
 import bench
@@ -20,3 +24,55 @@ def test_attention_bytes_match_survey_8d():
 def test_constants_name_baseline_config_2():
     assert (bench.BATCH, bench.LAT, bench.IMG, bench.CFG, bench.TOPK) == (32, 24, 384, 4.0, 2000)
     assert bench.HBM_PEAK_GBS == 8000.0
+
+
+def test_gpt_phase_bytes_match_survey_8d_config_2():
+    cfg = types.SimpleNamespace(dim=1024, n_head=16, n_layer=24, vocab_size=16384, ffn_dim_multiplier=None, multiple_of=256)
+    ph = bench.gpt_phase_bytes(cfg, 32, 576)
+    assert abs(ph["weights_per_step"] - 650.2e6) < 0.5e6 and ph["kv_bytes_per_token"] == 98304      # SURVEY 8 model table
+    assert ph["kv_reads"] == 98304 * 64 * 166176
+    total = sum(ph[k] for k in ("weights", "kv_reads", "kv_writes", "logits", "noise"))
+    assert abs(total - 1.426e12) < 0.005e12                                                          # "1.426 TB per 32 images"
+
+
+def _run_bench(args, env_extra=None, timeout=180):
+    env = dict(os.environ, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(os.path.dirname(bench.__file__), "bench.py")] + args, env=env,
+                          capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_gpus_2_launches_its_own_ranks_on_gloo():
+    """`python bench.py --gpus 2` with no launcher around it: the script re-runs itself under torch.distributed.run (one rank per
+    GPU), rank 0 prints ONE JSON line; here with the CPU stand-in for the device step (gloo, world_size 2)."""
+    r = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--standin"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["rccl_ranks"] == 2 and j["steps"] == 3 and j["warmup"] == 1 and j["scaling"] == "weak"
+    assert j["config"]["parallelism"] == "dp2" and "STAND-IN" in j["data"] and j["value"] > 0
+
+
+def test_bench_torchrun_form_and_world_mismatch():
+    """The driver's torchrun form keeps working (WORLD_SIZE set -> no self-launch), and a WORLD_SIZE that disagrees with --gpus
+    is refused."""
+    port = bench._free_port()
+    env = dict(os.environ, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(os.path.dirname(bench.__file__), "bench.py"), "--gpus", "2", "--steps", "2",
+                        "--warmup", "0", "--standin"], env=env, capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert sum(l.startswith("{") for l in r.stdout.splitlines()) == 1
+    r = _run_bench(["--gpus", "1", "--standin"], env_extra={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1",
+                                                            "MASTER_PORT": str(bench._free_port())}, timeout=60)
+    assert r.returncode != 0
+
+
+def test_bench_standin_single_rank():
+    r = _run_bench(["--standin", "--steps", "2", "--warmup", "0"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert j["n_gpus"] == 1 and j["rccl_ranks"] == 1

@@ -9,8 +9,9 @@ Same as the reference: one process per GPU, per-rank seed `global_seed * world +
 with `torch.randint` right before its generate() call (:128-133, so labels and sampling noise come out of the device generator
 in the reference's order), bicubic resize to `--image-size-eval`, uint8 HWC, global image index `i * world + rank + total`
 (:146), `<sample-dir>/<folder>.npz` with `arr_0` = the first `--num-fid-samples` images (:21-35).
-Different on purpose: `--lanes` batches are kept in flight per GPU (llamagen_amd.pipeline), the shards meet through ONE RCCL
-gather of uint8 images per iteration instead of PNG files on a shared filesystem (`--png` still writes them from rank 0), and
+Different on purpose: `--batches-per-chain` iterations share one decode chain and `--lanes` chains are kept in flight per GPU
+(llamagen_amd.pipeline), the shards meet through ONE RCCL gather of uint8 images per iteration instead of PNG files on a shared
+filesystem (`--png` still writes them from rank 0), every gathered batch is streamed to pinned host memory at once, and
 `--compile` is accepted and ignored.
 """
 import argparse
@@ -56,7 +57,10 @@ def build_parser():
     p.add_argument("--top-k", type=int, default=0, help="top-k value to sample with")
     p.add_argument("--temperature", type=float, default=1.0, help="temperature value to sample with")
     p.add_argument("--top-p", type=float, default=1.0, help="top-p value to sample with")
-    p.add_argument("--lanes", type=int, default=3, help="batches kept in flight per GPU")
+    p.add_argument("--lanes", type=int, default=2, help="decode chains kept in flight per GPU")
+    p.add_argument("--batches-per-chain", type=int, default=2, help="consecutive iterations (batches) that share one decode chain "
+                                                                    "(llamagen_amd.pipeline; every image is what its own generate() call "
+                                                                    "would produce from the same noise)")
     p.add_argument("--png", action="store_true", help="also write the individual .png files of the reference (rank 0)")
     return p
 
@@ -98,17 +102,28 @@ def main(args):
     def draw_labels():
         return torch.randint(0, args.num_classes, (n,), device=dev)
 
-    def finish(job_id, idx, img):  # on the lane's stream, as soon as decode_code() of that batch is enqueued
-        return ldist.gather_to_root(to_uint8_hwc(img, args.image_size_eval))  # [world * n, H, W, 3] in global index order on rank 0
+    # rank 0 keeps the result on the HOST: one pinned [total, H, W, 3] uint8 array that every iteration's gathered batch is
+    # copied into as soon as it exists (non-blocking, on that lane's stream), so the GPU never holds more than the batches in
+    # flight (50 000 x 256 x 256 x 3 = 9.8 GB would otherwise sit in HBM until the end)
+    E = args.image_size_eval
+    host = torch.empty((total_samples, E, E, 3), dtype=torch.uint8, pin_memory=True) if rank == 0 else None
 
-    pipe = SamplingPipeline(gpt_model, vq_model, lanes=max(1, min(args.lanes, iterations)))
-    outs = pipe.run([draw_labels] * iterations, latent ** 2, on_done=finish, cfg_scale=args.cfg_scale, cfg_interval=int(args.cfg_interval),
-                    temperature=args.temperature, top_k=args.top_k, top_p=args.top_p, sample_logits=True)
+    def finish(job_id, idx, img):  # on the lane's stream, as soon as decode_code() of that batch is enqueued
+        g = ldist.gather_to_root(to_uint8_hwc(img, E))  # [world * n, H, W, 3] in global index order on rank 0, None elsewhere
+        if g is not None:
+            host[job_id * global_batch:(job_id + 1) * global_batch].copy_(g, non_blocking=True)  # iteration t = indices t * global_batch ..
+        return None
+
+    bpc = max(1, args.batches_per_chain) if args.gpt_type == "c2i" else 1
+    chains = (iterations + bpc - 1) // bpc
+    pipe = SamplingPipeline(gpt_model, vq_model, lanes=max(1, min(args.lanes, chains)), batches_per_chain=bpc)
+    pipe.run([draw_labels] * iterations, latent ** 2, on_done=finish, cfg_scale=args.cfg_scale, cfg_interval=int(args.cfg_interval),
+             temperature=args.temperature, top_k=args.top_k, top_p=args.top_p, sample_logits=True)
     torch.cuda.synchronize(dev)
     npz_path = None
     if rank == 0:
-        arr = torch.cat([o.cpu() for o in outs]).numpy()[: args.num_fid_samples]   # iteration t holds global indices t * global_batch ..
-        assert arr.shape == (min(args.num_fid_samples, total_samples), args.image_size_eval, args.image_size_eval, 3) and arr.dtype == np.uint8
+        arr = host.numpy()[: args.num_fid_samples]
+        assert arr.shape == (min(args.num_fid_samples, total_samples), E, E, 3) and arr.dtype == np.uint8
         if args.png:
             from PIL import Image
             for i, a in enumerate(arr):

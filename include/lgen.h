@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LGEN_ABI_VERSION 5
+#define LGEN_ABI_VERSION 6
 #define LGEN_BF16 0
 #define LGEN_F32 1
 #define LGEN_F16 2   /* fp16 storage: BF16's layouts (KC = 32, EPL = 8), IEEE half rounding, v_mfma_f32_16x16x32_f16 */
@@ -232,6 +232,14 @@ int lgen_to_uint8_hwc(const float* in_nchw, unsigned char* out_nhwc, int B, int 
  * issues fire-and-forget reads of [next_weights, +bytes) -- the weight matrix of the kernel that follows it in
  * the decode chain -- so that the successor starts on a warm memory-side cache.  NULL clears it. */
 int lgen_prefetch_hint(const void* next_weights, long long bytes);
+
+/* One-shot schedule (per host thread) of the next FUSED-NORM lgen_gemm / lgen_gemm_qkv_rope[_rows] launch (ABI v6): the
+ * workgroup keeps its normalised activation rows in registers and walks `passes` consecutive n-groups (mt x nt tiles each),
+ * so that `attention_norm` / `ffn_norm` / `norm` (gpt.py:253-256, 367) are evaluated once per `passes` n-groups and the weight
+ * stream of group g+1 overlaps the reduction / epilogue of group g; `double_buffer` != 0 keeps the next group's weights in a
+ * second register set.  Like the prefetch hint it is baked into the launch's kernel arguments (graph-capture safe) and then
+ * cleared; launches without a fused norm ignore it.  Results are identical for every (passes, double_buffer). */
+int lgen_gemm_schedule_hint(int passes, int double_buffer);
 
 /* ---- tuning knobs (process-wide kernel variant selection; defaults are the measured-best ones) ---- */
 int lgen_set_attn_variant(int v);  /* (K/V loads per buffer, waves per (b,h)): 2 (default) = (2,2); 1 = (2,4); 0 = (4,4); 3 = (4,2); 4 = (2,1); 5 = (4,1) */

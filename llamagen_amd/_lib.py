@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblgen_hip.so")
 BF16, F32, F16 = 0, 1, 2
 EPI_ROWS, EPI_PACKED, EPI_GELU, EPI_RES, EPI_SWIGLU, EPI_QKV = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 5
+ABI_VERSION = 6
 SSQ_STRIDE = 256  # LGEN_SSQ_STRIDE: floats per row of a fused-RMSNorm statistics array
 ERR_UNSUPPORTED = -2
 
@@ -36,6 +36,7 @@ SIGNATURES = {
     "lgen_resize_bicubic": [_P, _P, _I, _I, _I, _I, _I, _P],
     "lgen_to_uint8_hwc": [_P, _P, _I, _I, _I, _I, _P],
     "lgen_prefetch_hint": [_P, _c.c_longlong],
+    "lgen_gemm_schedule_hint": [_I, _I],
     "lgen_set_attn_variant": [_I],
     "lgen_set_igemm_variant": [_I],
     "lgen_set_prefill_mfma": [_I],

@@ -8,6 +8,7 @@ ones do not; KV-cache buffers never match).  The VQ tokenizer is always `checkpo
 """
 from __future__ import annotations
 
+import argparse
 from typing import Any, Dict, Mapping, Union
 
 import torch
@@ -25,15 +26,25 @@ def pick_state_dict(checkpoint: Mapping[str, Any], from_fsdp: bool = False) -> D
     raise Exception("please check model weight, maybe add --from-fsdp to run command")  # sample_c2i.py:58
 
 
-def _read(src: Union[str, Mapping[str, Any]]):
-    return torch.load(src, map_location="cpu") if isinstance(src, (str, bytes)) or hasattr(src, "read") else src
+def _read(src: Union[str, Mapping[str, Any]], trusted: bool = False):
+    """torch.load of a reference-format checkpoint file.  The reference's trainers save more than tensors
+    (autoregressive/train/train_c2i.py:229-236: {"model", "optimizer", "steps", "args": argparse.Namespace}); torch >= 2.6
+    unpickles with weights_only=True by default and would reject the Namespace, so it is allow-listed explicitly.  `trusted=True`
+    is the reference's own behaviour (sample_c2i.py:49: plain torch.load, full unpickling) for checkpoints that carry other
+    Python objects -- only for files you would also hand to the reference."""
+    if not (isinstance(src, (str, bytes)) or hasattr(src, "read")):
+        return src
+    if trusted:
+        return torch.load(src, map_location="cpu", weights_only=False)
+    with torch.serialization.safe_globals([argparse.Namespace]):
+        return torch.load(src, map_location="cpu", weights_only=True)
 
 
-def load_gpt_checkpoint(model: torch.nn.Module, src: Union[str, Mapping[str, Any]], from_fsdp: bool = False):
+def load_gpt_checkpoint(model: torch.nn.Module, src: Union[str, Mapping[str, Any]], from_fsdp: bool = False, trusted: bool = False):
     """sample_c2i.py:48-61: sniff the wrapper key, drop buffers that are not parameters here (`freqs_cis`,
     `layers.N.attention.kv_cache.*`, `causal_mask`), `load_state_dict(strict=False)`.  Returns the (missing, unexpected)
     key lists so that a caller can insist on a complete load."""
-    sd = pick_state_dict(_read(src), from_fsdp)
+    sd = pick_state_dict(_read(src, trusted), from_fsdp)
     sd = {k: v for k, v in sd.items() if k != "freqs_cis" and "kv_cache" not in k and k != "causal_mask"}
     res = model.load_state_dict(sd, strict=False)
     if hasattr(model, "_engine"):
@@ -41,9 +52,9 @@ def load_gpt_checkpoint(model: torch.nn.Module, src: Union[str, Mapping[str, Any
     return list(res.missing_keys), list(res.unexpected_keys)
 
 
-def load_vq_checkpoint(model: torch.nn.Module, src: Union[str, Mapping[str, Any]]):
+def load_vq_checkpoint(model: torch.nn.Module, src: Union[str, Mapping[str, Any]], trusted: bool = False):
     """sample_c2i.py:32-33: `vq_model.load_state_dict(checkpoint["model"])` (strict)."""
-    ck = _read(src)
+    ck = _read(src, trusted)
     model.load_state_dict(ck["model"])
     if hasattr(model, "_engine"):
         model._engine = None

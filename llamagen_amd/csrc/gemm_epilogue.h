@@ -25,6 +25,8 @@ struct GemmArgs {
     float eps, inv_k;
     const char* pf;      // weights of the NEXT kernel of the chain (nullable): pulled towards the memory-side cache
     long long pf_bytes;
+    int passes;          // fused-norm GEMMs: consecutive n-groups one workgroup walks with its activations kept in registers (>= 1)
+    int db;              // fused-norm GEMMs: weights of the next n-group in a second register set (1) or reloaded after the MFMAs (0)
 };
 // weight chunk load: default cache policy (chains in flight share the weights through the memory-side cache; measured better than
 // non-temporal).  One plain load, NOT a run-time choice of policy: a branch per load makes the compiler lose count of the loads in
@@ -257,3 +259,4 @@ template <int EPI> constexpr bool epi_has_aux() { return EPI == EPI_RES || EPI =
 // returns LGEN_ERR_UNSUPPORTED when the shape is outside its envelope (caller falls back).
 int lgen_gemm_normpre_try(const GemmArgs& a, int epi, int dtype, int mt, int nt, int kw, hipStream_t st);
 void lgen_take_prefetch_hint(const char** p, long long* n);  // gemm_skinny.hip
+void lgen_take_schedule_hint(int* passes, int* db);            // gemm_skinny.hip

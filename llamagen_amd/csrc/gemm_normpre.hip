@@ -14,46 +14,32 @@
 // Loads retire in issue order, so step 3 waits only for the loads of step 1.
 #include "gemm_epilogue.h"
 
-template <typename D, int MT, int NT, int EPI, int CPW>
-__global__ __launch_bounds__(512) void gemm_normpre_kernel(GemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float4 red[];
-    constexpr int TILES = NT * MT;
-    constexpr int UNITS = EPI == EPI_SWIGLU ? (TILES / 2 > 0 ? TILES / 2 : 1) : TILES;
-    constexpr int UPW = (UNITS + 1) / 2;
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int KW = blockDim.x >> 6;  // KCH == KW * CPW (checked by the launcher)
-    const int nt0 = blockIdx.x * NT;
-    const int mt0 = blockIdx.y * MT;
-    const int k0 = w * CPW;
-    int posr[MT];
-    load_row_pos<MT, EPI>(a, mt0, lane, posr);
-
-    const unsigned pf_token = prefetch_lines(a.pf, a.pf_bytes, (blockIdx.y * gridDim.x + blockIdx.x) * KW + w,
-                                             gridDim.x * gridDim.y * KW, lane);
-    // 1. activations, norm weights, row statistics
-    uint4 B[CPW][MT], WN[CPW];
-    const uint4* xbase = a.xp + (size_t)mt0 * 64 + lane;
-    const size_t xstride = (size_t)a.MTs * 64;
-#pragma unroll
-    for (int c = 0; c < CPW; ++c) {
-#pragma unroll
-        for (int i = 0; i < MT; ++i) B[c][i] = xbase[(size_t)(k0 + c) * xstride + i * 64];
-        WN[c] = a.nw[(size_t)(k0 + c) * 4 + (lane >> 4)];
-    }
-    SsqLoads<ssq_nv<MT>()> sl[MT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i) sl[i] = ssq_issue<ssq_nv<MT>()>(a.ssq_in, a.parts, (mt0 + i) * 16 + (lane & 15), lane);
-    float ssum[MT];  // rows too wide to hold their partials across the weight requests: reduce them now (one or two L2 round trips)
-    if (!sl[0].fast) ssq_rows_now<MT>(a.ssq_in, a.parts, mt0, lane, ssum);
-    // 2. every weight chunk of this wave + the epilogue's memory operands
-    uint4 A[CPW][NT];
-    const uint4* wbase = a.wp + ((size_t)nt0 * a.KCH) * 64 + lane;
-    const size_t wstride = (size_t)a.KCH * 64;
+// Round 3: the kernel is PERSISTENT ALONG N ("x-stationary").  A workgroup keeps its normalised activation fragments in
+// registers and walks `passes` consecutive n-groups (NT 16-row tiles of N each): the activation / statistics loads, the RMSNorm
+// VALU work and the workgroup's start-up latency are paid once per workgroup instead of once per n-group, and the weight loads
+// of n-group g+1 are in flight while n-group g is reduced through LDS and stored (DB: one whole n-group ahead, in a second
+// register set, so that they also cover the MFMAs).  Measured motivation (profiles/r03_sq_pmc.csv): waves of the one-pass form
+// spend 58-63 % of their cycles parked on s_waitcnt / barriers with one workgroup per CU, i.e. the load phase and the compute
+// phase of a CU never overlap.  passes == 1 is the round-2 kernel.
+//
+// Workgroup -> (n-group range, m-group): a 1-D grid, decoded so that the m-groups that read the SAME weights sit on the same XCD
+// (block id b runs on XCD b % 8) in adjacent dispatch slots: one L2 fill serves all of them.
+template <int MT, int NT, int CPW>
+LGEN_DEV void np_load_w(uint4 (&A)[CPW][NT], const uint4* wbase, size_t wstride) {
 #pragma unroll
     for (int c = 0; c < CPW; ++c)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) A[c][j] = ldg_w(wbase + j * wstride + (size_t)(k0 + c) * 64);
+        for (int j = 0; j < NT; ++j) A[c][j] = ldg_w(wbase + j * wstride + (size_t)c * 64);
+}
+
+// MFMAs of one n-group, `between()` (the caller's next weight request), cross-wave K reduction through LDS in a fixed order
+// (wave 0, 1, 2, ...) and the fused epilogue.  `red` is this pass's reduction buffer.
+template <typename D, int MT, int NT, int EPI, int CPW, typename F>
+LGEN_DEV void np_pass(const GemmArgs& a, const uint4 (&A)[CPW][NT], const uint4 (&B)[CPW][MT], float4* red, int w, int KW, int lane,
+                      int nt0, int mt0, const int (&posr)[MT], F&& between) {
+    constexpr int TILES = NT * MT;
+    constexpr int UNITS = EPI == EPI_SWIGLU ? (TILES / 2 > 0 ? TILES / 2 : 1) : TILES;
+    constexpr int UPW = (UNITS + 1) / 2;
     uint4 aux[UNITS];
 #pragma unroll
     for (int q = 0; q < UNITS; ++q) aux[q] = make_uint4(0, 0, 0, 0);
@@ -67,17 +53,6 @@ __global__ __launch_bounds__(512) void gemm_normpre_kernel(GemmArgs a) {
             }
         }
     }
-    // 3. RMSNorm in registers (gpt.py:143-148), fixed-order statistics
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        float s = sl[i].fast ? ssq_finish(sl[i]) : ssum[i];
-        s += __shfl_xor(s, 16, 64);
-        s += __shfl_xor(s, 32, 64);
-        const float ri = 1.0f / sqrtf(s * a.inv_k + a.eps);
-#pragma unroll
-        for (int c = 0; c < CPW; ++c) B[c][i] = D::norm_chunk(B[c][i], ri, WN[c]);
-    }
-    // 4. MFMAs
     f32x4_t acc[NT][MT];
 #pragma unroll
     for (int j = 0; j < NT; ++j)
@@ -89,9 +64,7 @@ __global__ __launch_bounds__(512) void gemm_normpre_kernel(GemmArgs a) {
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < NT; ++j) acc[j][i] = D::mma(A[c][j], B[c][i], acc[j][i]);
-
-    prefetch_retire(a.pf, pf_token);
-
+    between();
     if (KW == 1) {
 #pragma unroll
         for (int q = 0; q < UNITS; ++q) {
@@ -105,7 +78,6 @@ __global__ __launch_bounds__(512) void gemm_normpre_kernel(GemmArgs a) {
         }
         return;
     }
-    // cross-wave K reduction through LDS, fixed summation order (wave 0, 1, 2, ...)
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -138,21 +110,154 @@ __global__ __launch_bounds__(512) void gemm_normpre_kernel(GemmArgs a) {
     }
 }
 
-template <int MT, int NT, int EPI, int CPW>
-static int launch_np(const GemmArgs& a, int kw, hipStream_t st) {
-    // shapes whose operand set does not fit 256 VGPRs (they spill; found by compiling everything once):
-    constexpr bool spills = (MT == 4 && CPW == 6) || (MT == 4 && NT == 4 && CPW == 5) ||
-                            (MT == 4 && NT >= 2 && EPI == EPI_QKV && CPW >= 5) ||
-                            (MT == 4 && NT == 4 && EPI == EPI_QKV) || (MT == 2 && NT == 4 && EPI == EPI_QKV && CPW == 6);
-    if constexpr (spills) {
+// reduction buffers: two (ping-pong, one barrier per pass) when both fit the 160 KiB of LDS with 8 K-splitting waves
+template <int MT, int NT>
+constexpr bool np_red2() { return 2 * 8 * NT * MT <= 160; }
+
+// MODE 0: one n-group per workgroup (the round-2 kernel); 1: `passes` n-groups, weights reloaded after each group's MFMAs;
+// 2: `passes` n-groups, the next group's weights in a second register set
+template <typename D, int MT, int NT, int EPI, int CPW, int MODE>
+__global__ __launch_bounds__(512) void gemm_normpre_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float4 red[];
+    constexpr int TILES = NT * MT;
+    constexpr bool RED2 = np_red2<MT, NT>();
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int KW = blockDim.x >> 6;  // KCH == KW * CPW (checked by the launcher)
+    // block id -> (bx = n-group range, by = m-group), the m-groups of one range on one XCD
+    const int gy = a.MTs / MT;
+    const int ngroups = (a.N / 16) / NT;
+    const int passes = MODE == 0 ? 1 : a.passes;
+    const int gx = (ngroups + passes - 1) / passes;
+    const int bid = blockIdx.x, slot = bid >> 3;
+    const int by = slot % gy, bx = (slot / gy) * 8 + (bid & 7);
+    if (bx >= gx) return;  // padding of the decoded grid (whole workgroup, before any barrier)
+    const int g0 = bx * passes;
+    const int np = (ngroups - g0) < passes ? (ngroups - g0) : passes;
+    const int mt0 = by * MT;
+    const int k0 = w * CPW;
+    int posr[MT];
+    load_row_pos<MT, EPI>(a, mt0, lane, posr);
+
+    const unsigned pf_token = prefetch_lines(a.pf, a.pf_bytes, bid * KW + w, gridDim.x * KW, lane);
+    // 1. activations, norm weights, row statistics
+    uint4 B[CPW][MT], WN[CPW];
+    const uint4* xbase = a.xp + (size_t)mt0 * 64 + lane;
+    const size_t xstride = (size_t)a.MTs * 64;
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) B[c][i] = xbase[(size_t)(k0 + c) * xstride + i * 64];
+        WN[c] = a.nw[(size_t)(k0 + c) * 4 + (lane >> 4)];
+    }
+    SsqLoads<ssq_nv<MT>()> sl[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) sl[i] = ssq_issue<ssq_nv<MT>()>(a.ssq_in, a.parts, (mt0 + i) * 16 + (lane & 15), lane);
+    float ssum[MT];  // rows too wide to hold their partials across the weight requests: reduce them now (one or two L2 round trips)
+    if (!sl[0].fast) ssq_rows_now<MT>(a.ssq_in, a.parts, mt0, lane, ssum);
+    // 2. every weight chunk of this wave for the first n-group
+    const size_t wstride = (size_t)a.KCH * 64;
+    const size_t gstride = wstride * NT;                  // uint4s between consecutive n-groups
+    const uint4* wbase = a.wp + (size_t)g0 * gstride + (size_t)k0 * 64 + lane;
+    uint4 A0[CPW][NT];
+    np_load_w<MT, NT, CPW>(A0, wbase, wstride);
+    // 3. RMSNorm in registers (gpt.py:143-148), fixed-order statistics, while (2) is in flight
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        float s = sl[i].fast ? ssq_finish(sl[i]) : ssum[i];
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        const float ri = 1.0f / sqrtf(s * a.inv_k + a.eps);
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) B[c][i] = D::norm_chunk(B[c][i], ri, WN[c]);
+    }
+    // 4. the n-groups of this workgroup
+    const size_t rstride = RED2 ? (size_t)KW * TILES * 64 : 0;
+    if constexpr (MODE == 0) {
+        np_pass<D, MT, NT, EPI, CPW>(a, A0, B, red, w, KW, lane, g0 * NT, mt0, posr, []() {});
+    } else if constexpr (MODE == 1) {
+        for (int p = 0; p < np; ++p) {
+            np_pass<D, MT, NT, EPI, CPW>(a, A0, B, red + (p & 1) * rstride, w, KW, lane, (g0 + p) * NT, mt0, posr, [&]() {
+                if (p + 1 < np) np_load_w<MT, NT, CPW>(A0, wbase + (size_t)(p + 1) * gstride, wstride);  // registers just consumed
+            });
+            if (!RED2 && p + 1 < np) __syncthreads();  // next pass rewrites `red`
+        }
+    } else {
+        // weights one whole n-group ahead in a second register set; every load below is unconditional inside its block, so
+        // the compiler keeps counted waits (a load under `if` makes the join wait for vmcnt(0))
+        uint4 A1[CPW][NT];
+        int p = 0;
+        while (p + 2 < np) {
+            np_load_w<MT, NT, CPW>(A1, wbase + (size_t)(p + 1) * gstride, wstride);
+            np_pass<D, MT, NT, EPI, CPW>(a, A0, B, red, w, KW, lane, (g0 + p) * NT, mt0, posr, []() {});
+            if (!RED2) __syncthreads();
+            np_load_w<MT, NT, CPW>(A0, wbase + (size_t)(p + 2) * gstride, wstride);
+            np_pass<D, MT, NT, EPI, CPW>(a, A1, B, red + rstride, w, KW, lane, (g0 + p + 1) * NT, mt0, posr, []() {});
+            if (!RED2) __syncthreads();
+            p += 2;
+        }
+        if (np - p == 2) {
+            np_load_w<MT, NT, CPW>(A1, wbase + (size_t)(p + 1) * gstride, wstride);
+            np_pass<D, MT, NT, EPI, CPW>(a, A0, B, red, w, KW, lane, (g0 + p) * NT, mt0, posr, []() {});
+            if (!RED2) __syncthreads();
+            np_pass<D, MT, NT, EPI, CPW>(a, A1, B, red + rstride, w, KW, lane, (g0 + p + 1) * NT, mt0, posr, []() {});
+        } else {
+            np_pass<D, MT, NT, EPI, CPW>(a, A0, B, red, w, KW, lane, (g0 + p) * NT, mt0, posr, []() {});
+        }
+    }
+    prefetch_retire(a.pf, pf_token);
+}
+
+// shapes whose operand set does not fit 256 VGPRs or that leave objects in scratch (found by compiling everything once and
+// reading csrc/gemm_normpre.usage); the multi-pass modes exist for the tile shapes the engine's heuristics can pick
+template <int MT, int NT, int EPI, int CPW, int MODE>
+constexpr bool np_spills() {
+    if (MODE > 0) {
+        if (!((MT == 1 && NT == 4) || (MT == 2 && NT == 2) || (MT == 2 && NT == 4) || (MT == 4 && NT == 2))) return true;
+        if (MT == 4 && (EPI == EPI_QKV || CPW >= 5)) return true;
+        if (MODE == 2 && CPW * NT * 8 + CPW * MT * 4 + NT * MT * 4 > (EPI == EPI_QKV ? 180 : 200)) return true;  // + a second weight set
+        if (MT == 2 && NT == 4 && EPI == EPI_QKV && CPW >= 5) return true;
+        return false;
+    }
+    if (MT == 2 && NT == 1 && EPI == EPI_QKV) return true;  // 40 B of scratch; a tuning-only shape (fused qkv runs nt = 4)
+    return (MT == 4 && CPW == 6) || (MT == 4 && NT == 4 && CPW == 5) || (MT == 4 && NT >= 2 && EPI == EPI_QKV && CPW >= 5) ||
+           (MT == 4 && NT == 4 && EPI == EPI_QKV) || (MT == 2 && NT == 4 && EPI == EPI_QKV && CPW == 6);
+}
+
+template <int MT, int NT, int EPI, int CPW, int MODE>
+static int launch_np2(const GemmArgs& a, int kw, hipStream_t st) {
+    if constexpr (np_spills<MT, NT, EPI, CPW, MODE>()) {
         return LGEN_ERR_UNSUPPORTED;
     } else {
-        dim3 grid((a.N / 16) / NT, a.MTs / MT);
-        const size_t lds = kw > 1 ? (size_t)kw * NT * MT * 64 * sizeof(float4) : 0;
-        hipLaunchKernelGGL((gemm_normpre_kernel<BF16, MT, NT, EPI, CPW>), grid, dim3(64 * kw), lds, st, a);
+        const int passes = MODE == 0 ? 1 : a.passes;
+        const int gy = a.MTs / MT, ngroups = (a.N / 16) / NT;
+        const int gx = (ngroups + passes - 1) / passes;
+        dim3 grid(8 * ((gx + 7) / 8) * gy);   // decoded in the kernel: m-groups of one n-range on one XCD, padding exits
+        const size_t one = kw > 1 ? (size_t)kw * NT * MT * 64 * sizeof(float4) : 0;
+        const size_t lds = (np_red2<MT, NT>() && MODE > 0) ? 2 * one : one;
+        if (lds > 160 * 1024) return LGEN_ERR_UNSUPPORTED;
+        auto kern = gemm_normpre_kernel<BF16, MT, NT, EPI, CPW, MODE>;
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+        }
+        hipLaunchKernelGGL(kern, grid, dim3(64 * kw), lds, st, a);
         LGEN_CHECK_LAUNCH();
         return 0;
     }
+}
+
+template <int MT, int NT, int EPI, int CPW>
+static int launch_np(const GemmArgs& a, int kw, hipStream_t st) {
+    if (a.passes > 1) {  // falls back mode by mode: double-buffered -> reload-after-MFMA -> one pass per workgroup
+        if (a.db) {
+            const int rc = launch_np2<MT, NT, EPI, CPW, 2>(a, kw, st);
+            if (rc != LGEN_ERR_UNSUPPORTED) return rc;
+        }
+        const int rc = launch_np2<MT, NT, EPI, CPW, 1>(a, kw, st);
+        if (rc != LGEN_ERR_UNSUPPORTED) return rc;
+    }
+    return launch_np2<MT, NT, EPI, CPW, 0>(a, kw, st);
 }
 
 template <int MT, int NT, int EPI>

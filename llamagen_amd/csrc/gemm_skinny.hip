@@ -274,6 +274,20 @@ void lgen_take_prefetch_hint(const char** p, long long* n) {
     g_pf_ptr = nullptr; g_pf_bytes = 0;
 }
 
+// One-shot host-side schedule of the next fused-norm lgen_gemm / lgen_gemm_qkv_rope launch of this thread (baked into that
+// launch's kernel arguments like the prefetch hint): n-groups per workgroup and weight double-buffering (gemm_normpre.hip).
+thread_local int g_sched_passes = 1, g_sched_db = 0;
+extern "C" int lgen_gemm_schedule_hint(int passes, int double_buffer) {
+    if (passes < 1 || passes > 64) return LGEN_ERR_BAD_ARG;
+    g_sched_passes = passes;
+    g_sched_db = double_buffer ? 1 : 0;
+    return 0;
+}
+void lgen_take_schedule_hint(int* passes, int* db) {
+    *passes = g_sched_passes; *db = g_sched_db;
+    g_sched_passes = 1; g_sched_db = 0;
+}
+
 extern "C" int lgen_gemm_max_kw(int epilogue_kind, int fused_norm, int mt, int nt) {
     switch (epilogue_kind) {
         case LGEN_EPI_ROWS: return fused_norm ? max_kw_of<EPI_ROWS, true>(mt, nt) : max_kw_of<EPI_ROWS, false>(mt, nt);
@@ -298,6 +312,7 @@ extern "C" int lgen_gemm(const void* wp, const void* xp, void* out, int M, int M
     a.nw = (const uint4*)norm_w; a.ssq_in = ssq_in; a.parts = ssq_parts; a.eps = eps; a.inv_k = 1.0f / (float)K;
     a.ssq_out = ssq_out;
     lgen_take_prefetch_hint(&a.pf, &a.pf_bytes);
+    lgen_take_schedule_hint(&a.passes, &a.db);
     hipStream_t st = (hipStream_t)stream;
     if (ssq_out && epilogue_kind != LGEN_EPI_RES) return LGEN_ERR_BAD_ARG;
     switch (epilogue_kind) {
@@ -327,6 +342,7 @@ static int qkv_rope_impl(const void* wp, const void* xp, void* q_out, void* k_ca
     if (a.kvs < hdp) return LGEN_ERR_BAD_ARG;
     a.nw = (const uint4*)norm_w; a.ssq_in = ssq_in; a.parts = ssq_parts; a.eps = eps; a.inv_k = 1.0f / (float)d;
     lgen_take_prefetch_hint(&a.pf, &a.pf_bytes);
+    lgen_take_schedule_hint(&a.passes, &a.db);
     return dispatch_norm<EPI_QKV>(a, dtype, mt, nt, kw, (hipStream_t)stream);
 }
 

@@ -53,6 +53,7 @@ struct SampleArgs {
 // bins.  Rows the histogram cannot resolve (more than SMP_CAND values in the critical bin, e.g. constant
 // rows, or non-finite values) take the exact MSB-first radix select on an LDS copy instead.
 #define SMP_NS 2
+static_assert(SMP_NS == 2, "the top-p tie ranking (tie_w[0] / tie_w[1], index order (s, thread, e)) is written for two slices per thread");
 #define SMP_NB 4096
 #define SMP_CAND 1024
 

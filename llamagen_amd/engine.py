@@ -196,6 +196,16 @@ class DecodeEngine:
             if len(t) != 3:
                 raise ValueError(f"LGEN_TILES: '{item}' is not kind=mt,nt,kw")
             self.tile_override[kind.strip()] = t
+        # fused-norm GEMM schedule (lgen_gemm_schedule_hint): kind -> (passes, double_buffer); LGEN_PASSES="qkv=2,1;w13=3,0"
+        self.pass_override = {}
+        for item in filter(None, os.environ.get("LGEN_PASSES", "").split(";")):
+            kind, _, val = item.partition("=")
+            if kind.strip() not in ("qkv", "w13", "head"):
+                raise ValueError(f"LGEN_PASSES: unknown fused-norm GEMM '{kind}'")
+            t = tuple(int(v) for v in val.split(","))
+            if len(t) != 2 or t[0] < 1:
+                raise ValueError(f"LGEN_PASSES: '{item}' is not kind=passes,double_buffer")
+            self.pass_override[kind.strip()] = t
         self._pack(model)
 
     # ---- weights --------------------------------------------------------------------------
@@ -263,11 +273,26 @@ class DecodeEngine:
         kw = max(1, min(kmax, 16 if kch >= 64 else 8, kch // 2))
         return mt, nt, kw
 
+    def _passes(self, kind: str, N: int, tiles):
+        """(passes, double_buffer) of a fused-norm GEMM: n-groups one workgroup walks with its normalised rows kept in registers
+        (gemm_normpre.hip).  One workgroup of these kernels fills a CU, so the (n-group, m-group) units are dealt out as
+        ~one workgroup per CU: ceil(units / 256) passes each."""
+        if kind in self.pass_override:
+            return self.pass_override[kind]
+        if not (self.fuse_norm and kind in ("qkv", "w13", "head")):
+            return 1, 0
+        mt, nt, _ = tiles
+        units = (N // 16 // nt) * (self.MTs // max(1, math.gcd(self.MTs, mt)))
+        passes = max(1, -(-units // 256))
+        return passes, 1 if passes > 1 else 0
+
     # ---- launches -----------------------------------------------------------------------------
-    def gemm(self, wp, xp, out, M, mts, N, K, epi, tiles, norm_w=None, ssq_out=None):
+    def gemm(self, wp, xp, out, M, mts, N, K, epi, tiles, norm_w=None, ssq_out=None, sched=None):
         mt, nt, kw = tiles
         if mts % mt:
             mt = math.gcd(mts, mt)
+        if sched is not None and sched[0] > 1 and norm_w is not None:
+            L.check(self.lib.lgen_gemm_schedule_hint(int(sched[0]), int(sched[1])), "lgen_gemm_schedule_hint")
         L.check(self.lib.lgen_gemm(L.ptr(wp), L.ptr(xp), L.ptr(out), M, mts, N, K, epi, self.dt, mt, nt, kw,
                                    L.ptr(norm_w), L.ptr(self.ssq) if norm_w is not None else 0, self.ssq_parts, self.eps,
                                    L.ptr(ssq_out), L.stream()), "lgen_gemm")
@@ -288,6 +313,7 @@ class DecodeEngine:
                                self._tiles("w2", d, F), self._tiles("head", self.V, d))
         pm = self._mask()
         ssq = self.ssq if fuse else None
+        sq, s13, sh = self._passes("qkv", 3 * d, tq), self._passes("w13", 2 * F, t13), self._passes("head", self.V, th)
 
         def hint(t):
             if self.prefetch:
@@ -300,6 +326,8 @@ class DecodeEngine:
             else:
                 L.check(lib.lgen_rmsnorm(L.ptr(self.hp), L.ptr(w["an"]), L.ptr(self.xnp), mts, d, self.eps, dt, st), "rmsnorm")
                 x_in, nw = self.xnp, None
+            if fuse and sq[0] > 1:
+                L.check(lib.lgen_gemm_schedule_hint(sq[0], sq[1]), "lgen_gemm_schedule_hint")
             L.check(qkv_fn(L.ptr(w["wqkv"]), L.ptr(x_in), L.ptr(self.qbuf), L.ptr(self.k_cache[i]),
                            L.ptr(self.v_cache[i]), L.ptr(self.freqs_cis), pos_ptr, M, mts, d, H, hd, hdp,
                            S8, self.kvs, dt, tq[0], tq[1], tq[2], L.ptr(nw), L.ptr(ssq), self.ssq_parts, self.eps, st),
@@ -322,7 +350,7 @@ class DecodeEngine:
                 L.check(lib.lgen_rmsnorm(L.ptr(self.hp), L.ptr(w["fn"]), L.ptr(self.xnp), mts, d, self.eps, dt, st), "rmsnorm")
                 x_in, nw = self.xnp, None
             hint(w["w2"])
-            self.gemm(w["w13"], x_in, self.gp, M, mts, 2 * F, d, L.EPI_SWIGLU, t13, norm_w=nw)
+            self.gemm(w["w13"], x_in, self.gp, M, mts, 2 * F, d, L.EPI_SWIGLU, t13, norm_w=nw, sched=s13)
             hint(self.layers[i + 1]["wqkv"] if i + 1 < nlayers else self.out_w)
             self.gemm(w["w2"], self.gp, self.hp, M, mts, d, F, L.EPI_RES, t2, ssq_out=ssq)
         if want_logits:
@@ -332,7 +360,7 @@ class DecodeEngine:
                 L.check(lib.lgen_rmsnorm(L.ptr(self.hp), L.ptr(self.norm_w), L.ptr(self.xnp), mts, d, self.eps, dt, st), "rmsnorm")
                 x_in, nw = self.xnp, None
             hint(self.layers[0]["wqkv"])  # the next decode step starts there
-            self.gemm(self.out_w, x_in, self.logits, M, mts, self.V, d, L.EPI_ROWS, th, norm_w=nw)
+            self.gemm(self.out_w, x_in, self.logits, M, mts, self.V, d, L.EPI_ROWS, th, norm_w=nw, sched=sh)
 
     def launches_per_step(self) -> int:
         """Kernel launches of one captured decode step (embed + L layers + norm/lm_head + sampler)."""
@@ -470,17 +498,28 @@ class DecodeEngine:
         else:
             L.check(lib.lgen_rmsnorm(L.ptr(self.hp), L.ptr(self.norm_w), L.ptr(self.xnp), mts, d, self.eps, dt, st), "rmsnorm")
             x_in, nw = self.xnp, None
-        self.gemm(self.out_w, x_in, self.logits, M, mts, self.V, d, L.EPI_ROWS, th, norm_w=nw)
+        self.gemm(self.out_w, x_in, self.logits, M, mts, self.V, d, L.EPI_ROWS, th, norm_w=nw, sched=self._passes("head", self.V, th))
 
     # ---- Exp(1) noise: what torch.multinomial draws, one [B, V] fp32 exponential_ per sampled token ----
+    def _noise_buffer(self, N, B):
+        if self.noise is None or self.noise.shape[0] < N or self.noise.shape[1] != B:
+            self.noise = torch.empty(N, B, self.V, dtype=torch.float32, device=self.dev)
+        return self.noise
+
+    def draw_noise(self, N, B, b0, n):
+        """The N x [n, V] exponential_ draws of ONE batch of a chain (images b0 .. b0 + n - 1 of B): the same calls, in the same
+        order, that this batch's own generate() would make (each [n, V] slice is one contiguous block of the chain's buffer)."""
+        buf = self._noise_buffer(N, B)
+        for j in range(N):
+            buf[j, b0:b0 + n].exponential_(1.0)
+
     def _noise_begin(self, N, B, noise_seq):
         """noise[i] feeds the sampler of step i.  Injected (tests) or drawn from the device's default
         generator in the reference's order -- N separate [B, V] exponential_ calls -- up front on the
         calling stream (N x ~5 us, < 1 % of a generate()), so that no RNG launch sits inside the captured
         decode step.  (A side stream would overlap it, but HIP maps streams onto 4 hardware queues and a
         lane's side stream then queues behind another lane's whole decode loop.)"""
-        if self.noise is None or self.noise.shape[0] < N or self.noise.shape[1] != B:
-            self.noise = torch.empty(N, B, self.V, dtype=torch.float32, device=self.dev)
+        self._noise_buffer(N, B)
         if noise_seq is not None:
             self.noise[:N].copy_(noise_seq[:N].to(self.dev))
             return
@@ -513,8 +552,9 @@ class DecodeEngine:
             cm |= torch.eye(self.S8, dtype=torch.bool, device=self.dev)
             self.use_mask = True
         noise_seq = sp.pop("_noise_seq", None)
+        prefilled = sp.pop("_noise_prefilled", False)  # generate.py drew it batch by batch (chains of several batches)
         sampling = bool(sp["sample_logits"])
-        if sampling:
+        if sampling and not prefilled:
             self._noise_begin(N, B, noise_seq)
         # ---- prefill (generate.py:77-86): state = (pos, step) = (T-1, 0) when the first token is sampled
         if model.model_type == "c2i":
@@ -534,7 +574,8 @@ class DecodeEngine:
         self._sample(B, sp)
         yield 0
         # ---- decode (generate.py:105-123): every step first advances (pos, step)
-        key = (B, N, self._mask() is not None, self.fuse_norm, tuple(sorted(self.tile_override.items())), sp["use_cfg"], sp["cfg_scale"],
+        key = (B, N, self._mask() is not None, self.fuse_norm, tuple(sorted(self.tile_override.items())),
+               tuple(sorted(self.pass_override.items())), sp["use_cfg"], sp["cfg_scale"],
                sp["cfg_interval"], sp["temperature"], sp["top_k"], sp["top_p"], sp["sample_logits"],
                self.noise.data_ptr() if sampling else 0)
         use_graph = os.environ.get("LGEN_NO_GRAPH") is None and N > 3

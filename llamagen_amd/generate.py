@@ -40,6 +40,11 @@ def generate_iter(model, cond, max_new_tokens, emb_masks=None, cfg_scale=1.0, cf
     top_p = sampling_kwargs.pop("top_p", 1.0)
     sample_logits = sampling_kwargs.pop("sample_logits", True)
     noise_seq = sampling_kwargs.pop("_noise_seq", None)  # test hook: inject the Exp(1) draws [N, B, V]
+    # pipeline hook (llamagen_amd/pipeline.py, batches_per_chain > 1): `cond` is the FIRST batch of a chain and these callables
+    # yield the conditioning of the batches that share its decode chain.  They are evaluated in the order consecutive reference
+    # generate() calls would consume the default generator: labels of batch j, then batch j's N x [n, V] Exp(1) draws, then
+    # labels of batch j + 1, ... (sample_c2i_ddp.py:128-140) -- so a seeded run is the same whatever the chain width.
+    more_conds = sampling_kwargs.pop("_more_conds", None)
     if sampling_kwargs:
         raise TypeError(f"unexpected sampling arguments: {sorted(sampling_kwargs)}")
 
@@ -47,8 +52,25 @@ def generate_iter(model, cond, max_new_tokens, emb_masks=None, cfg_scale=1.0, cf
     if kind not in ("c2i", "t2i"):
         raise Exception("please check model type")
     use_cfg = cfg_scale > 1.0
-    B = cond.shape[0]
     prefix = 1 if kind == "c2i" else cond.shape[1]          # conditioning positions in front of the image tokens
+    prefilled = False
+    if more_conds:
+        if kind != "c2i" or noise_seq is not None:
+            raise NotImplementedError("_more_conds: class-conditional chains without injected noise")
+        n, groups = cond.shape[0], 1 + len(more_conds)
+        model.setup_caches(max_batch_size=(2 if use_cfg else 1) * n * groups, max_seq_length=prefix + max_new_tokens,
+                           dtype=model.tok_embeddings.weight.dtype)
+        parts = [cond]
+        for j in range(groups):
+            if j > 0:
+                parts.append(more_conds[j - 1]() if callable(more_conds[j - 1]) else more_conds[j - 1])
+                if parts[-1].shape != cond.shape:
+                    raise ValueError("batches that share a chain must have the same size")
+            if sample_logits:
+                model._engine.draw_noise(max_new_tokens, n * groups, j * n, n)
+        cond = torch.cat(parts)
+        prefilled = bool(sample_logits)
+    B = cond.shape[0]
     rows = torch.cat([cond, _null_condition(model, cond)]) if use_cfg else cond   # CFG: conditional rows, then their twins
     model.setup_caches(max_batch_size=rows.shape[0], max_seq_length=prefix + max_new_tokens,
                        dtype=model.tok_embeddings.weight.dtype)
@@ -63,4 +85,6 @@ def generate_iter(model, cond, max_new_tokens, emb_masks=None, cfg_scale=1.0, cf
               sample_logits=bool(sample_logits))
     if noise_seq is not None:
         sp["_noise_seq"] = noise_seq
+    if prefilled:
+        sp["_noise_prefilled"] = True
     return (yield from model._engine.generate_iter(model, rows, B, max_new_tokens, masks, sp))

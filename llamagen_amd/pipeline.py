@@ -71,7 +71,7 @@ class SamplingLane:
     def start(self, job_id, cond, max_new_tokens, decode_shape, gen_kw):
         cur = torch.cuda.current_stream(self.dev)
         self.stream.wait_stream(cur)  # inputs produced on the caller's stream
-        self._job = (job_id, cond.shape[0], max_new_tokens, decode_shape)
+        self._job = (job_id, cond.shape[0] * (1 + len(gen_kw.get("_more_conds") or ())), max_new_tokens, decode_shape)
         with torch.cuda.stream(self.stream), torch.no_grad():
             self._it = generate_iter(self.gpt, cond, max_new_tokens, **gen_kw)
             next(self._it)  # noise draws + prefill + first token
@@ -125,6 +125,12 @@ class SamplingPipeline:
         # (2 x 256 threads x 186 VGPRs), so nothing of the decode lanes co-resides with them; confining the decoder to N
         # CUs (one shared, CU-masked stream) leaves the other CUs to the latency-bound decode chains
         n_cu = torch.cuda.get_device_properties(self.dev).multi_processor_count if torch.cuda.is_available() else 256
+        if vq_cus < 0 or vq_cus >= n_cu:
+            raise ValueError(f"vq_cus must satisfy 0 <= vq_cus < {n_cu} (an all-zero CU mask cannot run anything)")
+        if lanes_avoid_vq_cus and vq_cus == 0:
+            raise ValueError("lanes_avoid_vq_cus needs vq_cus > 0")
+        if lanes_avoid_vq_cus and (cu_partition or os.environ.get("LGEN_LANE_CU_MASK", "0") == "1"):
+            raise ValueError("lanes_avoid_vq_cus and cu_partition both define the lanes' CU masks: use one of them")
         if vq is not None and vq_cus > 0:
             words = [0] * ((n_cu + 31) // 32)
             for b in range(min(vq_cus, n_cu)):
@@ -178,14 +184,27 @@ class SamplingPipeline:
                 if not lane.busy and nxt < len(conds):
                     # a callable is evaluated only now, so that a driver can draw its labels from the device generator in the
                     # reference's order (labels of batch i, noise of batch i, labels of batch i+1, ...: sample_c2i_ddp.py:128-140)
-                    group = [c() if callable(c) else c for c in conds[nxt:nxt + self.bpc]]
-                    rows = group[0].shape[0]
-                    if any(c.shape[0] != rows for c in group):
-                        raise ValueError("batches that share a chain must have the same size")
-                    # a last, incomplete group repeats its last batch (rows computed and dropped): one chain shape per lane
-                    chain = group[0] if self.bpc == 1 else torch.cat(group + [group[-1]] * (self.bpc - len(group)))
-                    shape = None if decode_shape is None else [chain.shape[0]] + list(decode_shape[1:])
-                    lane.start((nxt, len(group), rows), chain, max_new_tokens, shape, gen_kw)
+                    group = list(conds[nxt:nxt + self.bpc])
+                    if self.bpc == 1:
+                        chain = group[0]() if callable(group[0]) else group[0]
+                        rows, kw = chain.shape[0], gen_kw
+                        shape = decode_shape
+                    else:
+                        # the chain's first batch now; the others are evaluated by generate_iter in RNG order (labels of batch j,
+                        # noise of batch j, labels of batch j + 1, ...).  A last, incomplete group repeats its last batch (rows
+                        # computed and dropped): one chain shape per lane
+                        chain = group[0]() if callable(group[0]) else group[0]
+                        rows = chain.shape[0]
+                        more = group[1:] + [group[-1] if not callable(group[-1]) else (lambda c=chain: c)] * (self.bpc - len(group))
+                        if "_noise_seq" in gen_kw:  # injected noise (tests): evaluate now, the whole chain's block is given
+                            parts = [chain] + [c() if callable(c) else c for c in more]
+                            if any(c.shape[0] != rows for c in parts):
+                                raise ValueError("batches that share a chain must have the same size")
+                            chain, kw = torch.cat(parts), gen_kw
+                        else:
+                            kw = dict(gen_kw, _more_conds=more)
+                        shape = None if decode_shape is None else [rows * self.bpc] + list(decode_shape[1:])
+                    lane.start((nxt, len(group), rows), chain, max_new_tokens, shape, kw)
                     nxt += len(group)
             active = [lane for lane in self.lanes if lane.busy]
             if not active:

@@ -36,6 +36,7 @@ class ContinuousBatcher:
         if dev.type != "cuda":
             raise RuntimeError("llamagen_amd.serve runs only on an AMD GPU through the HIP library (no CPU fallback)")
         self.model, self.dev = model, dev
+        self.num_classes, self.V = int(model.num_classes), int(model.config.vocab_size)
         self.B, self.N = slots, max_new_tokens
         self.use_cfg = cfg_scale > 1.0
         self.B2 = 2 * slots if self.use_cfg else slots
@@ -64,9 +65,17 @@ class ContinuousBatcher:
     # ---- requests ---------------------------------------------------------------------------------------------------
     def submit(self, class_label: int, noise: Optional[torch.Tensor] = None) -> int:
         """Queue one image request; `noise` (optional, [N, V] fp32 Exp(1) draws) replaces the default generator's draw."""
+        label = int(class_label)
+        if not 0 <= label <= self.num_classes:  # num_classes itself is the null class (LabelEmbedder table row, gpt.py:66-72);
+            raise IndexError(f"class label {label} outside [0, {self.num_classes}]")  # the reference's nn.Embedding raises too
+        if noise is not None:
+            if self.noise is None:
+                raise ValueError("noise given but the batcher was built with sample_logits=False (greedy)")
+            if tuple(noise.shape) != (self.N, self.V):
+                raise ValueError(f"noise must be [{self.N}, {self.V}] fp32 Exp(1) draws, got {tuple(noise.shape)}")
         rid = self._next_id
         self._next_id += 1
-        self._queue.append((rid, int(class_label), noise))
+        self._queue.append((rid, label, noise))
         return rid
 
     def _load(self, b: int, rid: int, label: int, noise):

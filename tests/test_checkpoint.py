@@ -45,3 +45,36 @@ def test_vq_checkpoint_is_strict(tmp_path):
     bad.pop("post_quant_conv.bias")
     with pytest.raises(RuntimeError):
         load_vq_checkpoint(vq, {"model": bad})
+
+
+class _Opaque:  # stands for any non-tensor Python object a training script may have pickled next to the weights
+    def __init__(self):
+        self.x = 3
+
+
+def test_reference_ddp_training_checkpoint_with_args_namespace(tmp_path):
+    """The layout autoregressive/train/train_c2i.py:229-236 writes: {"model", "optimizer", "steps", "args": argparse.Namespace}.
+    torch >= 2.6 unpickles weights_only by default; the Namespace must not make the load fail."""
+    import argparse
+    m = Transformer(ModelArgs(**KW))
+    sd = synth_for_module(m, seed=5)
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-4)
+    ck = {"model": dict(sd), "optimizer": opt.state_dict(), "steps": 1234,
+          "args": argparse.Namespace(gpt_model="GPT-B", image_size=256, lr=1e-4, results_dir="results")}
+    path = tmp_path / "0001234.pt"
+    torch.save(ck, path)
+    missing, unexpected = load_gpt_checkpoint(m, str(path))
+    assert missing == [] and unexpected == []
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+
+
+def test_checkpoint_with_foreign_objects_needs_trusted(tmp_path):
+    m = Transformer(ModelArgs(**KW))
+    sd = synth_for_module(m, seed=6)
+    path = tmp_path / "odd.pt"
+    torch.save({"model": dict(sd), "extra": _Opaque()}, path)
+    with pytest.raises(Exception):
+        load_gpt_checkpoint(m, str(path))                       # safe unpickling refuses the unknown class
+    missing, unexpected = load_gpt_checkpoint(m, str(path), trusted=True)   # the reference's plain torch.load
+    assert missing == [] and unexpected == []

@@ -78,7 +78,8 @@ def test_sample_c2i_ddp_driver_equals_sequential_loop(tmp_path):
     torch.save({"model": vsd}, tmp_path / "vq.pt")
     argv = ["--gpt-model", "GPT-B", "--gpt-ckpt", str(tmp_path / "c2i_B_256.pt"), "--vq-ckpt", str(tmp_path / "vq.pt"), "--image-size", "256",
             "--image-size-eval", "256", "--precision", "bf16", "--global-seed", "3", "--cfg-scale", "2.0", "--top-k", "500",
-            "--per-proc-batch-size", "2", "--num-fid-samples", "5", "--sample-dir", str(tmp_path / "samples"), "--lanes", "2"]
+            "--per-proc-batch-size", "2", "--num-fid-samples", "5", "--sample-dir", str(tmp_path / "samples"), "--lanes", "2",
+            "--batches-per-chain", "2"]  # iterations 0 and 1 share a 8-row chain; labels / noise still in the reference's RNG order
     path = ex.main(ex.build_parser().parse_args(argv))
     arr = np.load(path)["arr_0"]
     assert arr.shape == (5, 256, 256, 3) and arr.dtype == np.uint8 and "GPT-B-c2i_B_256-size-256-size-256-VQ-16-topk-500" in path
@@ -95,3 +96,54 @@ def test_sample_c2i_ddp_driver_equals_sequential_loop(tmp_path):
         ref.append(to_uint8_hwc(vq.decode_code(ids, [2, 8, lat, lat])).cpu())
     ref = torch.cat(ref).numpy()[:5]
     np.testing.assert_array_equal(arr, ref)
+
+
+def test_sample_t2i_driver_matches_oracle(tmp_path):
+    """examples/sample_t2i.py (reference flags, T5 features from a file): the left-padding rotation, `embs * masks`, generate() with
+    emb_masks and decode_code of sample_t2i.py:95-123, token ids held to the oracle bit for bit (fp32)."""
+    spec = importlib.util.spec_from_file_location("example_sample_t2i", os.path.join(ROOT, "examples", "sample_t2i.py"))
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    dev = torch.device("cuda:0")
+    lat, T, C = 16, 120, 2048
+    kw = dict(n_layer=2, n_head=4, dim=256, vocab_size=16384, block_size=lat * lat, cls_token_num=T, caption_dim=C, model_type="t2i")
+    from llamagen_amd.gpt import ModelArgs, Transformer
+    gpt = Transformer(ModelArgs(**kw))
+    gsd = synth_for_module(gpt, seed=51, lin_std=0.05)
+    torch.save({"model": gsd}, tmp_path / "t2i.pt")
+    vq = VQ_models["VQ-16"](codebook_size=16384, codebook_embed_dim=8)
+    vsd = synth_for_module(vq, seed=52)
+    torch.save({"model": vsd}, tmp_path / "vq.pt")
+    g = torch.Generator().manual_seed(9)
+    lens = [7, 33, 120]
+    embs = torch.randn(3, T, C, generator=g)
+    masks = torch.zeros(3, T, dtype=torch.int64)
+    for b, n in enumerate(lens):
+        masks[b, :n] = 1                                   # right-padded, as the T5 tokenizer emits them
+    np.savez(tmp_path / "t5.npz", caption_embs=embs.numpy(), emb_masks=masks.numpy())
+    # the example builds its model from the registry; give it this small architecture under a registry name
+    ex.GPT_models["GPT-tiny-t2i"] = lambda **k: Transformer(ModelArgs(**{**kw, **{a: b for a, b in k.items() if a in ("block_size", "cls_token_num", "model_type")}}))
+    argv = ["--gpt-model", "GPT-tiny-t2i", "--gpt-ckpt", str(tmp_path / "t2i.pt"), "--vq-ckpt", str(tmp_path / "vq.pt"), "--image-size", "256",
+            "--precision", "none", "--seed", "11", "--cfg-scale", "7.5", "--top-k", "1000", "--t5-feature-path", str(tmp_path / "t5.npz"),
+            "--out", str(tmp_path / "t2i.png")]
+    try:
+        res = ex.main(ex.build_parser().parse_args(argv))   # the registry key above is a valid --gpt-model choice now
+    finally:
+        ex.GPT_models.pop("GPT-tiny-t2i", None)
+    toks = res["index_sample"]
+    N = lat * lat
+    assert toks.dtype == torch.int32 and tuple(toks.shape) == (3, N)
+    # independent restatement of sample_t2i.py:95-108 for the oracle
+    lp = torch.stack([torch.cat([embs[b, n:], embs[b, :n]]) for b, n in enumerate(lens)])
+    lm = torch.flip(masks, dims=[-1])
+    c = lp * lm[:, :, None]
+    assert torch.equal(res["c_indices"].cpu().float(), c) and torch.equal(res["c_emb_masks"].cpu(), lm)
+    torch.manual_seed(11)
+    qs = iter([torch.empty(3, 16384, device=dev).exponential_(1).cpu() for _ in range(N)])
+    cfg = O.GPTConfig(**{k: v for k, v in kw.items()})
+    ref = O.generate(O.GPTOracle(cfg, gsd, torch.float32), c, N, emb_masks=lm, cfg_scale=7.5, cfg_interval=-1, temperature=1.0,
+                     top_k=1000, top_p=1.0, sample_logits=True, noise_fn=lambda s: next(qs))
+    np.testing.assert_array_equal(toks.cpu().numpy(), ref.numpy())
+    img_ref = O.vq_decode_code(vsd, ref.long(), [3, 8, lat, lat])
+    assert (res["samples"].cpu() - img_ref).abs().max().item() < 1e-3
+    assert os.path.exists(res["path"])

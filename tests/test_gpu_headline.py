@@ -1,5 +1,5 @@
 """Parity of the kernels `bench.py` actually times (BASELINE config 2: GPT-L bf16, fused-norm tiles, 32 x 24 x 24
-decode_code; 64 rows = one batch per chain, 128 rows = the default two batches per chain) and of the config 3-5 kernel
+decode_code; 64 rows = one batch per chain, 128 / 256 rows = two / four batches per chain) and of the config 3-5 kernel
 shapes against the CPU oracle.
 
 The small-model tests of test_gpu_gpt.py pin the arithmetic; these pin the *instantiations*: the
@@ -174,6 +174,83 @@ def test_config2_gptl_bf16_two_batches_per_chain_logits_vs_oracle():
     assert e.fuse_norm and e.MTs == 8 and e.S8 == 584
     assert e._tiles("qkv", 3 * e.d, e.d) == (2, 4, 8) and e._tiles("w13", 2 * e.F, e.d) == (2, 4, 8)  # what bench.py replays
     _check("config2_gptl_b128", recs)
+
+
+def test_config2_gptl_bf16_four_batches_per_chain_logits_vs_oracle():
+    """Round 3 schedule: four batches of 32 share one decode chain -> 256 rows, MTs = 16, the fused-norm GEMMs walk several
+    n-groups per workgroup (lgen_gemm_schedule_hint): prefill, positions 1..2 and position 299 on injected cache contents, same
+    bar as the 64-row test."""
+    case = dict(registry="GPT-L", kwargs=dict(vocab_size=16384, block_size=576, num_classes=1000, cls_token_num=1,
+                                              model_type="c2i"), wseed=21, lin_std=0.02)
+    B = 128
+    cond = torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(5))
+    recs, m = _teacher_forced(case, B, 4.0, early=2, late=[299], cond=cond)
+    e = m._engine
+    assert e.fuse_norm and e.MTs == 16 and e.S8 == 584
+    assert e._passes("w13", 2 * e.F, e._tiles("w13", 2 * e.F, e.d))[0] > 1   # the persistent form is what ran
+    _check("config2_gptl_b256", recs)
+
+
+@pytest.mark.parametrize("M", [64, 128, 256])
+def test_fused_norm_gemm_passes_bit_identical(M):
+    """gemm_normpre.hip walks `passes` n-groups per workgroup with its normalised rows kept in registers (round 3).  The
+    arithmetic per output element does not depend on the schedule: qkv (+RoPE+append), w1||w3 (+SwiGLU) and lm_head outputs at
+    GPT-L sizes must be BIT-identical for every (passes, double_buffer), including pass counts that do not divide the n-groups,
+    and the one-pass result is held to the oracle."""
+    from llamagen_amd.engine import pack_act, pack_weight, precompute_freqs_cis_2d, unpack_act
+    from tests.test_gpu_gpt import _close, _rand
+    L, dev = _L(), _dev()
+    lib = L.lib()
+    dt, d, H, hd, F, V, grid, pos = torch.bfloat16, 1024, 16, 64, 2816, 4096, 24, 77
+    S8 = O.find_multiple(1 + grid * grid, 8)
+    mts = M // 16
+    x = _rand((M, d), dt, 51, 1.3)
+    nw = (1 + 0.1 * _rand((d,), torch.float32, 52)).to(dt)
+    wq, w1, w3, wh = _rand((3 * d, d), dt, 53, 0.03), _rand((F, d), dt, 54, 0.03), _rand((F, d), dt, 55, 0.03), _rand((V, d), dt, 56, 0.03)
+    freqs = precompute_freqs_cis_2d(grid, hd, 10000.0, 1)
+    xp, nw_d, fr_d = pack_act(x.to(dev), mts), nw.to(dev), freqs.to(dev)
+    wqp, whp = pack_weight(wq.to(dev)), pack_weight(wh.to(dev))
+    w13 = torch.stack([pack_weight(w1.to(dev)), pack_weight(w3.to(dev))], dim=1).flatten(0, 1).contiguous()
+    ssq = torch.full((mts * 16, L.SSQ_STRIDE), float("nan"), device=dev)
+    L.check(lib.lgen_ssq_pack(L.ptr(xp), L.ptr(ssq), mts, d, L.BF16, L.stream()), "ssq_pack")
+    state = torch.tensor([pos, 0], dtype=torch.int32, device=dev)
+
+    def run(tile, passes, db):
+        mt, nt = tile
+        kc = torch.zeros(M, H, S8, 64, dtype=dt, device=dev)
+        vc = torch.zeros(M, H, S8, 64, dtype=dt, device=dev)
+        q = torch.zeros(mts * 16, H, 64, dtype=dt, device=dev)
+        gp = torch.zeros(F // 32, mts, 64, 8, dtype=dt, device=dev)
+        rows = torch.zeros(mts * 16, V, dtype=dt, device=dev)
+        L.check(lib.lgen_gemm_schedule_hint(passes, db), "hint")
+        L.check(lib.lgen_gemm_qkv_rope(L.ptr(wqp), L.ptr(xp), L.ptr(q), L.ptr(kc), L.ptr(vc), L.ptr(fr_d), L.ptr(state), M, mts, d, H,
+                                       hd, 64, S8, 0, L.BF16, mt, nt, 8, L.ptr(nw_d), L.ptr(ssq), d // 16, 1e-5, L.stream()), "qkv")
+        L.check(lib.lgen_gemm_schedule_hint(passes, db), "hint")
+        L.check(lib.lgen_gemm(L.ptr(w13), L.ptr(xp), L.ptr(gp), M, mts, 2 * F, d, L.EPI_SWIGLU, L.BF16, mt, nt, 8, L.ptr(nw_d),
+                              L.ptr(ssq), d // 16, 1e-5, 0, L.stream()), "w13")
+        L.check(lib.lgen_gemm_schedule_hint(passes, db), "hint")
+        L.check(lib.lgen_gemm(L.ptr(whp), L.ptr(xp), L.ptr(rows), M, mts, V, d, L.EPI_ROWS, L.BF16, mt, nt, 8, L.ptr(nw_d),
+                              L.ptr(ssq), d // 16, 1e-5, 0, L.stream()), "head")
+        torch.cuda.synchronize()
+        return q, kc[:, :, pos].clone(), vc[:, :, pos].clone(), gp, rows
+
+    for tile in [(2, 4), (1, 4), (2, 2), (4, 2)]:
+        if tile[0] > mts:
+            continue
+        if tile == (4, 2):  # qkv (4, 2) has no multi-pass form (register budget): the library falls back to one pass, still identical
+            pass
+        base = run(tile, 1, 0)
+        for passes, db in [(2, 0), (2, 1), (3, 0), (3, 1), (5, 1), (7, 0), (64, 1)]:
+            got = run(tile, passes, db)
+            for name, a, b in zip(("q", "k", "v", "swiglu", "logits"), base, got):
+                assert torch.equal(a, b), (tile, passes, db, name, (a.float() - b.float()).abs().max().item())
+    q, k, v, gp, rows = base
+    xn = O.rms_norm(x.float(), nw, 1e-5, dt)
+    _close(rows[:M], O.linear(xn, wh.float(), dt), dt, "norm+lm_head", frac_ulp1=0.05)
+    a1, a3 = O.linear(xn, w1.float(), dt), O.linear(xn, w3.float(), dt)
+    _close(unpack_act(gp, M), O._rnd(O._rnd(torch.nn.functional.silu(a1), dt) * a3, dt), dt, "norm+swiglu", frac_ulp1=0.08, ulps=3)
+    qkv = O.linear(xn, wq.float(), dt)
+    _close(v, qkv[:, 2 * d:].reshape(M, H, hd), dt, "v row", frac_ulp1=0.05)
 
 
 @pytest.mark.parametrize("d,H,M,mt", [(1024, 16, 64, 1), (1280, 20, 64, 1), (1536, 24, 64, 1), (768, 12, 64, 1),

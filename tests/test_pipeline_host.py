@@ -17,6 +17,11 @@ class _Lane:
         return self.job is not None
 
     def start(self, job_id, cond, max_new_tokens, decode_shape, gen_kw):
+        # what generate_iter does with `_more_conds` (the other batches of the chain, evaluated in RNG order after the first)
+        parts = [cond] + [c() if callable(c) else c for c in (gen_kw.get("_more_conds") or [])]
+        if any(c.shape != cond.shape for c in parts):
+            raise ValueError("batches that share a chain must have the same size")
+        cond = torch.cat(parts)
         self.job, self.left = (job_id, cond.clone(), max_new_tokens, decode_shape), self.steps
         self.started.append((job_id, cond.clone(), decode_shape))
 

@@ -11,6 +11,7 @@ from llamagen_amd.serve import ContinuousBatcher
 class _Batcher(ContinuousBatcher):
     def __init__(self, slots, N, cfg=True):  # the real constructor builds a DecodeEngine on the GPU
         self.B, self.N, self.use_cfg = slots, N, cfg
+        self.num_classes, self.V = 1000, 32
         self.B2 = 2 * slots if cfg else slots
         R = 16
         self.dev = torch.device("cpu")
@@ -62,3 +63,19 @@ def test_late_submissions_join_a_running_batch_without_cfg_rows():
     assert first[a].tolist() == [5000, 5001, 5002, 5003]
     assert sorted(second) == [b, c, d] and second[d].tolist() == [8000, 8001, 8002, 8003]
     assert cb.steps_run == 4 + 8
+
+
+def test_submit_validates_label_and_noise():
+    import pytest
+    cb = _Batcher(slots=2, N=4)
+    with pytest.raises(IndexError):
+        cb.submit(1001)            # the reference's embedding lookup raises for labels outside the table (gpt.py:78-83)
+    with pytest.raises(IndexError):
+        cb.submit(-1)
+    cb.submit(1000)                # the null class is a valid table row
+    with pytest.raises(ValueError):
+        cb.submit(3, noise=torch.ones(4, 32))   # greedy batcher (no noise buffer)
+    cb.noise = torch.zeros(2, 4, 32)
+    with pytest.raises(ValueError):
+        cb.submit(3, noise=torch.ones(5, 32))
+    cb.submit(3, noise=torch.ones(4, 32))

@@ -32,7 +32,7 @@ def run(gpt, vq, B, lanes, images=384, tag="", reps=2):
         torch.cuda.synchronize(); dt = time.perf_counter() - t
         out.append(B * K / dt)
     print(f"{tag} B={B:3d} x {lanes} chains, K={K:2d}, vq={'y' if vq is not None else 'n'}: " + " / ".join(f"{v:6.1f}" for v in out) +
-          f" img/s   tiles='{os.environ.get('LGEN_TILES', '')}'", flush=True)
+          f" img/s   tiles='{os.environ.get('LGEN_TILES', '')}' passes='{os.environ.get('LGEN_PASSES', '')}'", flush=True)
     del pipe
     torch.cuda.empty_cache()
 
@@ -46,18 +46,22 @@ def main():
     except Exception as ex:  # noqa: BLE001
         print("no sweep result:", ex)
     for B, lanes, images in [(32, 1, 64), (64, 1, 128), (128, 1, 256), (128, 2, 512), (64, 3, 384)]:
-        for name, spec in (("default", ""), ("best", best.get(2 * B, ""))):
+        for name, spec in (("default", None), ("best", best.get(2 * B))):
             if name == "best" and not spec:
                 continue
-            os.environ["LGEN_TILES"] = spec
+            os.environ["LGEN_TILES"] = spec["tiles"] if spec else ""
+            os.environ["LGEN_PASSES"] = spec["passes"] if spec else ""
             try:
                 run(gpt, None, B, lanes, images=images, tag=f"R3A {name:7s}")
             except Exception as ex:  # noqa: BLE001
                 print(f"R3A {name} B={B} x {lanes}: failed: {ex!r}", flush=True)
     for B, lanes, images in [(128, 1, 256), (128, 2, 512), (64, 3, 384)]:
-        os.environ["LGEN_TILES"] = best.get(2 * B, "")
+        spec = best.get(2 * B)
+        os.environ["LGEN_TILES"] = spec["tiles"] if spec else ""
+        os.environ["LGEN_PASSES"] = spec["passes"] if spec else ""
         run(gpt, vq, B, lanes, images=images, tag="R3A best+vq")
     os.environ["LGEN_TILES"] = ""
+    os.environ["LGEN_PASSES"] = ""
 
 
 if __name__ == "__main__":

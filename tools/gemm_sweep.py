@@ -50,25 +50,28 @@ def sweep(m, rows, out):
     e.state.zero_()
     nl = len(e.layers)
 
-    def qkv(tl):
+    def qkv(tl, sc=(1, 0)):
         for w in e.layers:
+            if sc[0] > 1:
+                L.check(lib.lgen_gemm_schedule_hint(sc[0], sc[1]), "hint")
             L.check(lib.lgen_gemm_qkv_rope(L.ptr(w["wqkv"]), L.ptr(e.hp), L.ptr(e.qbuf), L.ptr(e.k_cache[0]), L.ptr(e.v_cache[0]),
                                            L.ptr(e.freqs_cis), L.ptr(e.state), M, mts, d, H, hd, hdp, S8, e.kvs, dt, tl[0], tl[1], tl[2],
                                            L.ptr(w["an"]), L.ptr(e.ssq), e.ssq_parts, e.eps, L.stream()), "qkv")
 
     kinds = {
         "qkv": (qkv, nl, 3 * d * d * 2),
-        "wo": (lambda tl: [e.gemm(w["wo"], e.ap, e.hp, M, mts, d, d, L.EPI_RES, tl, ssq_out=e.ssq) for w in e.layers], nl, d * d * 2),
-        "w13": (lambda tl: [e.gemm(w["w13"], e.hp, e.gp, M, mts, 2 * F, d, L.EPI_SWIGLU, tl, norm_w=w["fn"]) for w in e.layers], nl, 2 * F * d * 2),
-        "w2": (lambda tl: [e.gemm(w["w2"], e.gp, e.hp, M, mts, d, F, L.EPI_RES, tl, ssq_out=e.ssq) for w in e.layers], nl, F * d * 2),
-        "head": (lambda tl: [e.gemm(e.out_w, e.hp, e.logits, M, mts, V, d, L.EPI_ROWS, tl, norm_w=e.norm_w) for _ in range(4)], 4, V * d * 2),
+        "wo": (lambda tl, sc=None: [e.gemm(w["wo"], e.ap, e.hp, M, mts, d, d, L.EPI_RES, tl, ssq_out=e.ssq) for w in e.layers], nl, d * d * 2),
+        "w13": (lambda tl, sc=None: [e.gemm(w["w13"], e.hp, e.gp, M, mts, 2 * F, d, L.EPI_SWIGLU, tl, norm_w=w["fn"], sched=sc) for w in e.layers], nl, 2 * F * d * 2),
+        "w2": (lambda tl, sc=None: [e.gemm(w["w2"], e.gp, e.hp, M, mts, d, F, L.EPI_RES, tl, ssq_out=e.ssq) for w in e.layers], nl, F * d * 2),
+        "head": (lambda tl, sc=None: [e.gemm(e.out_w, e.hp, e.logits, M, mts, V, d, L.EPI_ROWS, tl, norm_w=e.norm_w, sched=sc) for _ in range(4)], 4, V * d * 2),
     }
+    scheds = [(1, 0), (2, 0), (2, 1), (3, 0), (3, 1), (4, 1), (6, 1), (8, 1)]
     cands = {
-        "qkv": [(a, b, 8) for a in (1, 2, 4) for b in (1, 2, 4)],
-        "w13": [(a, b, 8) for a in (1, 2, 4) for b in (2, 4)],
-        "head": [(a, b, 8) for a in (1, 2, 4) for b in (2, 4)],
-        "wo": [(a, b, k) for a in (1, 2, 4, 8) for b in (1, 2, 4) for k in (4, 8, 16)],
-        "w2": [(a, b, k) for a in (1, 2, 4, 8) for b in (1, 2, 4) for k in (8, 16)],
+        "qkv": [(1, 4, 8), (2, 4, 8), (2, 2, 8), (4, 2, 8), (4, 4, 8)],
+        "w13": [(1, 4, 8), (2, 4, 8), (2, 2, 8), (4, 2, 8), (4, 4, 8)],
+        "head": [(1, 4, 8), (2, 4, 8), (4, 2, 8), (4, 4, 8)],
+        "wo": [(1, 1, 8), (2, 1, 8), (4, 1, 8), (2, 2, 8), (2, 1, 4)],
+        "w2": [(1, 1, 16), (2, 1, 16), (2, 1, 8), (4, 1, 8), (2, 2, 8), (1, 2, 16)],
     }
     best = {}
     for kind, (fn, launches, nbytes) in kinds.items():
@@ -77,21 +80,26 @@ def sweep(m, rows, out):
         for tl in [default] + [c for c in cands[kind] if c != default]:
             if tl[0] > mts or mts % tl[0]:
                 continue
-            try:
-                us = timed_graph(lambda: fn(tl), launches)
-            except Exception as ex:  # noqa: BLE001 -- an uninstantiated / unsupported shape
-                torch.cuda.synchronize()
-                print(f"rows {rows:3d} {kind:5s} {tl}: unsupported ({str(ex)[:60]})", flush=True)
-                continue
-            tag = " (default)" if tl == default else ""
-            print(f"rows {rows:3d} {kind:5s} {str(tl):12s} {us:7.2f} us  {nbytes / us / 1e3:7.1f} GB/s{tag}", flush=True)
-            out.append(dict(rows=rows, kind=kind, tile=tl, us=round(us, 3), default=tl == default))
-            if kind not in best or us < best[kind][1]:
-                best[kind] = (tl, us)
-    spec = ";".join(f"{k}={t[0]},{t[1]},{t[2]}" for k, (t, _) in best.items())
-    tot = sum(us * (1 if k == "head" else nl) for k, (_, us) in best.items())
-    print(f"rows {rows}: best LGEN_TILES='{spec}'  -> {tot:.0f} us of GEMMs per decode step", flush=True)
-    return spec
+            for sc in (scheds if kind in ("qkv", "w13", "head") else [(1, 0)]):
+                units = ({"qkv": 3 * d, "w13": 2 * F, "head": V}.get(kind, d) // 16 // tl[1]) * (mts // tl[0])
+                if sc[0] > 1 and units // sc[0] < 64:
+                    continue  # fewer than 64 workgroups: not worth a measurement
+                try:
+                    us = timed_graph(lambda: fn(tl, sc), launches)
+                except Exception as ex:  # noqa: BLE001 -- an uninstantiated / unsupported shape
+                    torch.cuda.synchronize()
+                    print(f"rows {rows:3d} {kind:5s} {tl}: unsupported ({str(ex)[:60]})", flush=True)
+                    break
+                tag = " (default tile)" if tl == default else ""
+                print(f"rows {rows:3d} {kind:5s} {str(tl):12s} passes {sc[0]} db {sc[1]}  {us:7.2f} us  {nbytes / us / 1e3:7.1f} GB/s{tag}", flush=True)
+                out.append(dict(rows=rows, kind=kind, tile=tl, sched=sc, us=round(us, 3), default=tl == default))
+                if kind not in best or us < best[kind][2]:
+                    best[kind] = (tl, sc, us)
+    spec = ";".join(f"{k}={t[0]},{t[1]},{t[2]}" for k, (t, _, _) in best.items())
+    pspec = ";".join(f"{k}={sc[0]},{sc[1]}" for k, (_, sc, _) in best.items() if k in ("qkv", "w13", "head"))
+    tot = sum(us * (1 if k == "head" else nl) for k, (_, _, us) in best.items())
+    print(f"rows {rows}: best LGEN_TILES='{spec}' LGEN_PASSES='{pspec}'  -> {tot:.0f} us of GEMMs per decode step", flush=True)
+    return dict(tiles=spec, passes=pspec)
 
 
 def main():

@@ -55,13 +55,14 @@ class SamplingLane:
     tools/ubench_cp.py), so the default keeps the decoder on the lane's stream."""
 
     def __init__(self, gpt, vq=None, stream: Optional[torch.cuda.Stream] = None, primary: bool = False,
-                 vq_stream: Optional[torch.cuda.Stream] = None):
+                 vq_stream: Optional[torch.cuda.Stream] = None, vq_chunk: int = 0):
         self.gpt = gpt if primary else gpt.lane_view()
         self.vq = vq
         self.dev = next(gpt.parameters()).device
         self.stream = stream or torch.cuda.Stream(device=self.dev)
         self.vq_stream = vq_stream or self.stream
-        self._it = None
+        self.vq_chunk = int(vq_chunk)   # > 0: decode_code() in pieces of this many images (a chain of several batches decodes
+        self._it = None                 # batch by batch: activation tensors stay at the per-batch size, 2.4 GB at 32 x 384 px)
         self._job = None
 
     @property
@@ -93,7 +94,12 @@ class SamplingLane:
             idx.record_stream(self.vq_stream)
             with torch.cuda.stream(self.vq_stream), torch.no_grad():
                 lat = int(round(N ** 0.5))
-                img = self.vq.decode_code(idx, shape or [B, 8, lat, lat])
+                shp = list(shape or [B, 8, lat, lat])
+                if self.vq_chunk > 0 and B > self.vq_chunk:
+                    img = torch.cat([self.vq.decode_code(idx[i:i + self.vq_chunk], [min(self.vq_chunk, B - i)] + shp[1:])
+                                     for i in range(0, B, self.vq_chunk)])
+                else:
+                    img = self.vq.decode_code(idx, shp)
         self._it = None
         cur = torch.cuda.current_stream(self.dev)
         idx.record_stream(cur)
@@ -108,7 +114,7 @@ class SamplingPipeline:
 
     def __init__(self, gpt, vq=None, lanes: int = 2, steps_per_turn: int = 1, vq_low_priority: bool = False,
                  cu_partition: Optional[bool] = None, vq_cus: int = 0, lanes_avoid_vq_cus: bool = False,
-                 batches_per_chain: int = 1):
+                 batches_per_chain: int = 1, vq_chunk: int = 0):
         self.dev = next(gpt.parameters()).device
         # `batches_per_chain` consecutive batches of run() share ONE decode chain (their rows are concatenated): rows never
         # interact before the sampler and the sampler pairs row b with row B + b only, so every image is what its own
@@ -152,8 +158,8 @@ class SamplingPipeline:
         if cu_partition and lanes > 1:
             streams = [masked_stream(self.dev, cu_mask_words(n_cu, i, lanes)) for i in range(lanes)]
         self.cu_partition = bool(cu_partition and lanes > 1)
-        self.lanes: List[SamplingLane] = [SamplingLane(gpt, vq, stream=streams[i], primary=(i == 0), vq_stream=self.vq_stream)
-                                          for i in range(lanes)]
+        self.lanes: List[SamplingLane] = [SamplingLane(gpt, vq, stream=streams[i], primary=(i == 0), vq_stream=self.vq_stream,
+                                                       vq_chunk=vq_chunk) for i in range(lanes)]
         self.steps_per_turn = steps_per_turn
 
     def prepare(self, batch: int, max_new_tokens: int, **gen_kw):

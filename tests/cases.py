@@ -9,6 +9,7 @@ _HD100 = dict(n_layer=2, n_head=8, dim=800, vocab_size=2048, block_size=16, num_
 _T2I = dict(n_layer=2, n_head=4, dim=256, vocab_size=1024, block_size=16, cls_token_num=120,
             caption_dim=64, model_type="t2i")
 _GPTB = dict(vocab_size=16384, block_size=256, num_classes=1000, cls_token_num=1, model_type="c2i")
+_GPTL = dict(vocab_size=16384, block_size=576, num_classes=1000, cls_token_num=1, model_type="c2i")   # BASELINE configs[1]
 
 
 def _c(kwargs, **over):
@@ -40,6 +41,13 @@ GPT_CASES = {
                   trace_steps=[0, 1, 128, 255]),
     "gptb_cfg4": _c(_GPTB, registry="GPT-B", batch=2, n_new=24, cfg_scale=4.0, top_k=2000, lin_std=0.02,
                     trace_steps=[0, 1, 23]),
+    # BASELINE.json configs[1] at the reference itself (round 3): LlamaGen-L 384 px (24 layers, d 1024), cfg 4.0, top-k 2000.
+    # fp32: 24 free-running tokens, bit-exact.  bf16 (the reference default, sample_c2i.py:108): 8 teacher-forced steps; at depth
+    # 24 two correct bf16 evaluations differ by more than the 2-layer bar (GEMM accumulation order; the oracle's own fp32-vs-fp64
+    # distance is 3.9-6.7 / 0.58-0.83 ulp), hence the per-case bar.
+    "gptl_fp32": _c(_GPTL, registry="GPT-L", batch=2, n_new=24, cfg_scale=4.0, top_k=2000, lin_std=0.02, trace_steps=[0, 1, 23]),
+    "gptl_bf16": _c(_GPTL, registry="GPT-L", dtype="bf16", batch=2, n_new=8, cfg_scale=4.0, top_k=2000, lin_std=0.02,
+                    trace_steps=[0, 3, 7], ulp_max=8.0, ulp_mean=1.3, agree=0.5),
 }
 
 
@@ -67,6 +75,9 @@ VQ_CASES = {
     "vq8_4x4": dict(kind="decode", vq="VQ-8", codebook_size=16384, embed_dim=8, wseed=4, rseed=23, batch=2, h=4, w=4),
     "argmin_6x6": dict(kind="argmin", vq="VQ-16", codebook_size=16384, embed_dim=8, wseed=3, rseed=24, batch=2, h=6, w=6),
     "argmin_24x24": dict(kind="argmin", vq="VQ-16", codebook_size=16384, embed_dim=8, wseed=5, rseed=25, batch=2, h=24, w=24),
+    # BASELINE configs[1] decode shape: one 24 x 24 code grid -> 3 x 384 x 384 (stored as uint8 + every 8th pixel in fp32)
+    "vq16_24x24": dict(kind="decode", vq="VQ-16", codebook_size=16384, embed_dim=8, wseed=9, rseed=30, batch=1, h=24, w=24,
+                       store="sampled"),
     # encode(): Encoder convs (stride-2 Downsample) -> quant_conv -> argmin; h, w = IMAGE size
     "enc16_32x32": dict(kind="encode", vq="VQ-16", codebook_size=16384, embed_dim=8, wseed=6, rseed=26, batch=2, h=32, w=32),
     "enc16_48x32": dict(kind="encode", vq="VQ-16", codebook_size=16384, embed_dim=8, wseed=6, rseed=27, batch=1, h=48, w=32),

@@ -81,7 +81,10 @@ def run_vq_case(name, case):
     arrs = {}
     if case["kind"] == "decode":
         img = vq.decode_code(inp["codes"], inp["shape"])
-        arrs["image"] = img.numpy().astype(np.float32)
+        if case.get("store") == "sampled":   # big images: uint8 in full + every 8th pixel in fp32
+            arrs["image_s8"] = img[:, :, ::8, ::8].numpy().astype(np.float32)
+        else:
+            arrs["image"] = img.numpy().astype(np.float32)
         arrs["uint8"] = torch.clamp(127.5 * img + 128.0, 0, 255).permute(0, 2, 3, 1).to(torch.uint8).numpy()
         print(f"vq_{name}: image {tuple(img.shape)} range [{img.min():.3f}, {img.max():.3f}]")
     elif case["kind"] == "argmin":

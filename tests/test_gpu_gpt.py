@@ -424,8 +424,9 @@ def test_forward_teacher_forced_bf16(name):
     got = np.stack([got[int(s)].numpy() for s in gold["trace_steps"]])
     ulp = np.abs(ref).max() * (2.0 ** -8 if case["dtype"] == "bf16" else 2.0 ** -11)
     err = np.abs(got - ref)
-    assert err.max() <= 4 * ulp, (err.max(), ulp)
-    assert err.mean() <= (0.25 if case["dtype"] == "bf16" else 0.5) * ulp, (err.mean(), ulp)  # fp16 bar: see test_oracle_golden.py
+    print(name, "HIP vs reference golden: max %.2f ulp, mean %.3f ulp" % (err.max() / ulp, err.mean() / ulp))
+    assert err.max() <= case.get("ulp_max", 4.0) * ulp, (err.max(), ulp)  # depth-24 case: its own bar, tests/cases.py
+    assert err.mean() <= case.get("ulp_mean", 0.25 if case["dtype"] == "bf16" else 0.5) * ulp, (err.mean(), ulp)  # fp16 bar: see test_oracle_golden.py
 
 
 @pytest.mark.parametrize("name", ["tiny_cfg4", "hd100_cfg4", "tiny_nocfg_temp", "tiny_interval"])

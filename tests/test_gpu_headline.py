@@ -234,23 +234,30 @@ def test_fused_norm_gemm_passes_bit_identical(M):
         torch.cuda.synchronize()
         return q, kc[:, :, pos].clone(), vc[:, :, pos].clone(), gp, rows
 
-    for tile in [(2, 4), (1, 4), (2, 2), (4, 2)]:
+    xn = O.rms_norm(x.float(), nw, 1e-5, dt)
+    ref_rows = O.linear(xn, wh.float(), dt)
+    a1, a3 = O.linear(xn, w1.float(), dt), O.linear(xn, w3.float(), dt)
+    ref_gp = O._rnd(O._rnd(torch.nn.functional.silu(a1), dt) * a3, dt)
+    ref_v = O.linear(xn, wq.float(), dt)[:, 2 * d:].reshape(M, H, hd)
+    first = None
+    for tile in [(2, 4), (1, 4), (2, 2), (4, 2)]:  # qkv (4, 2) has no multi-pass form (register budget): falls back to one pass
         if tile[0] > mts:
             continue
-        if tile == (4, 2):  # qkv (4, 2) has no multi-pass form (register budget): the library falls back to one pass, still identical
-            pass
         base = run(tile, 1, 0)
         for passes, db in [(2, 0), (2, 1), (3, 0), (3, 1), (5, 1), (7, 0), (64, 1)]:
             got = run(tile, passes, db)
             for name, a, b in zip(("q", "k", "v", "swiglu", "logits"), base, got):
                 assert torch.equal(a, b), (tile, passes, db, name, (a.float() - b.float()).abs().max().item())
-    q, k, v, gp, rows = base
-    xn = O.rms_norm(x.float(), nw, 1e-5, dt)
-    _close(rows[:M], O.linear(xn, wh.float(), dt), dt, "norm+lm_head", frac_ulp1=0.05)
-    a1, a3 = O.linear(xn, w1.float(), dt), O.linear(xn, w3.float(), dt)
-    _close(unpack_act(gp, M), O._rnd(O._rnd(torch.nn.functional.silu(a1), dt) * a3, dt), dt, "norm+swiglu", frac_ulp1=0.08, ulps=3)
-    qkv = O.linear(xn, wq.float(), dt)
-    _close(v, qkv[:, 2 * d:].reshape(M, H, hd), dt, "v row", frac_ulp1=0.05)
+        # the K split (8 waves x 4 chunks, summed wave 0..7) is the same for every workgroup shape: tiles agree bit for bit too
+        if first is None:
+            first = base
+        for name, a, b in zip(("q", "k", "v", "swiglu", "logits"), first, base):
+            assert torch.equal(a, b), (tile, "vs first tile", name, (a.float() - b.float()).abs().max().item())
+        q, k, v, gp, rows = base
+        assert torch.isfinite(rows[:M].float()).all() and torch.isfinite(gp.float()).all()
+        _close(rows[:M], ref_rows, dt, f"norm+lm_head {tile}", frac_ulp1=0.05, ulps=2)
+        _close(unpack_act(gp, M), ref_gp, dt, f"norm+swiglu {tile}", frac_ulp1=0.08, ulps=3)
+        _close(v, ref_v, dt, f"v row {tile}", frac_ulp1=0.05, ulps=2)
 
 
 @pytest.mark.parametrize("d,H,M,mt", [(1024, 16, 64, 1), (1280, 20, 64, 1), (1536, 24, 64, 1), (768, 12, 64, 1),

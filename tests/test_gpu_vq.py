@@ -127,8 +127,14 @@ def test_decode_code_matches_reference_golden(name):
     m = m.to(_dev())
     inp = make_vq_inputs(case)
     img = m.decode_code(inp["codes"].to(_dev()), inp["shape"])
-    assert img.dtype == torch.float32 and tuple(img.shape) == gold["image"].shape
-    err = np.abs(img.cpu().numpy() - gold["image"]).max()
+    if "image" in gold:
+        assert img.dtype == torch.float32 and tuple(img.shape) == gold["image"].shape
+        err = np.abs(img.cpu().numpy() - gold["image"]).max()
+    else:  # BASELINE configs[1] decode shape: every 8th pixel in fp32 + the whole image as the uint8 the reference would write
+        assert img.dtype == torch.float32 and tuple(img.shape) == (case["batch"], 3, 16 * case["h"], 16 * case["w"])
+        err = np.abs(img[:, :, ::8, ::8].cpu().numpy() - gold["image_s8"]).max()
+        u8 = O.to_uint8_hwc(img.cpu()).numpy().astype(np.int32)
+        assert (np.abs(u8 - gold["uint8"].astype(np.int32)) <= 1).all() and (u8 != gold["uint8"]).mean() < 2e-3
     assert err < 1e-3, err
     ref = O.vq_decode_code(sd, inp["codes"], inp["shape"], ch_mult=tuple(m.config.decoder_ch_mult))
     assert (img.cpu() - ref).abs().max().item() < 1e-3

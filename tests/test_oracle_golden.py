@@ -51,12 +51,13 @@ def test_oracle_logits_teacher_forced_bf16(name):
     scale = np.abs(ref).max()
     ulp = scale * ULP[case["dtype"]]
     err = np.abs(got - ref)
-    assert err.max() <= 4 * ulp, (err.max(), ulp)
+    print(name, "oracle vs reference: max %.2f ulp, mean %.3f ulp" % (err.max() / ulp, err.mean() / ulp))
+    assert err.max() <= case.get("ulp_max", 4.0) * ulp, (err.max(), ulp)   # deep models carry their own bar (tests/cases.py)
     # fp16: torch-CPU's half GEMM is not a single-rounded fp32 accumulation (0.12 % of nn.Linear outputs differ from it,
     # measured; 0 % in bf16), so the fp16 golden itself carries ~1 extra flip per logit: mean bar 0.5 ulp instead of 0.25
-    assert err.mean() <= (0.5 if case["dtype"] == "fp16" else 0.25) * ulp, (err.mean(), ulp)
+    assert err.mean() <= case.get("ulp_mean", 0.5 if case["dtype"] == "fp16" else 0.25) * ulp, (err.mean(), ulp)
     agree = (toks.numpy() == gold["tokens"]).mean()
-    assert agree >= 0.8, agree  # sampler given near-identical logits and the same noise
+    assert agree >= case.get("agree", 0.8), agree  # sampler given near-identical logits and the same noise
 
 
 def test_multinomial_is_argmax_p_over_q():
@@ -80,7 +81,10 @@ def test_oracle_vq_decode(name):
     m, sd = build_vq_holder(case)
     inp = make_vq_inputs(case)
     img = O.vq_decode_code(sd, inp["codes"], inp["shape"], ch_mult=tuple(m.config.decoder_ch_mult))
-    np.testing.assert_allclose(img.numpy(), gold["image"], rtol=0, atol=5e-5)
+    if "image" in gold:
+        np.testing.assert_allclose(img.numpy(), gold["image"], rtol=0, atol=5e-5)
+    else:  # big image: the reference's pixels are stored at every 8th row / column in fp32 (+ uint8 in full below)
+        np.testing.assert_allclose(img[:, :, ::8, ::8].numpy(), gold["image_s8"], rtol=0, atol=5e-5)
     u8 = O.to_uint8_hwc(img).numpy()
     assert (np.abs(u8.astype(np.int32) - gold["uint8"].astype(np.int32)) <= 1).all()
     assert (u8 != gold["uint8"]).mean() < 1e-3

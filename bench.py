@@ -431,8 +431,8 @@ def standin_main(args, rank, local, world, rccl_ranks):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json configs[1..4]; 2 = the headline")
     ap.add_argument("--lanes", type=int, default=0, help="decode chains in flight per GPU (llamagen_amd/pipeline.py); "
                                                          "0 = pick 1..3 from the step count")
@@ -499,11 +499,14 @@ def main():
     if args.lanes <= 0:
         # k chains in flight take ~T_k (measured, relative to one chain alone: 1, 1.44, 2.02 at 64 rows; 1, 1.5, 2.1 at 128);
         # a run of C chains on L lanes costs floor(C/L) * T_L + T_(C mod L): use the cheapest L
-        Tk = {0: 0.0, 1: 1.0, 2: 1.44, 3: 2.02} if bpc == 1 else {0: 0.0, 1: 1.0, 2: 1.5, 3: 2.1}
+        # (round 3, 256-row chains with the decoder in 32-image pieces: 1, 1.71, 2.49 -- tools/exp_r3c.py)
+        Tk = {0: 0.0, 1: 1.0, 2: 1.44, 3: 2.02} if bpc == 1 else ({0: 0.0, 1: 1.0, 2: 1.5, 3: 2.1} if bpc < 4 else
+                                                                   {0: 0.0, 1: 1.0, 2: 1.71, 3: 2.49})
         args.lanes = min((1, 2, 3), key=lambda l: (chains // l) * Tk[l] + Tk[chains % l])
     pipe = SamplingPipeline(gpt, vq, lanes=args.lanes, steps_per_turn=args.steps_per_turn, vq_low_priority=args.vq_own_stream,
                             cu_partition=True if args.lane_cu_mask else None, vq_cus=args.vq_cus,
-                            lanes_avoid_vq_cus=args.lanes_avoid_vq_cus, batches_per_chain=bpc)
+                            lanes_avoid_vq_cus=args.lanes_avoid_vq_cus, batches_per_chain=bpc,
+                            vq_chunk=B if (bpc > 1 and args.lanes > 1) else 0)  # decode_code() batch by batch: finer interleaving
     pipe.prepare(B, N, **skw)  # setup (like loading weights): KV slabs, workspaces, decode graphs per lane
     torch.cuda.synchronize()
 
@@ -681,7 +684,7 @@ def main():
         dist.destroy_process_group()
 
 
-DEFAULT_BPC = 2          # c2i: consecutive batches per decode chain (128 rows at config 2)
+DEFAULT_BPC = 4          # c2i: consecutive batches per decode chain (256 rows at config 2)
 PMC_JSON = "r02_pmc.json"
 
 

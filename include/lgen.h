@@ -246,7 +246,7 @@ int lgen_set_attn_variant(int v);  /* (K/V loads per buffer, waves per (b,h)): 2
 int lgen_set_vq_nt(int v);         /* VQ decoder: non-temporal fp32 activation stores / GroupNorm-pass loads (0 = off) */
 int lgen_set_prefill_mfma(int v);       /* lgen_attn_prefill, bf16: 1 (default) MFMA flash kernel; 0 the VALU kernels (always used for fp32) */
 int lgen_set_conv_fused_variant(int v); /* lgen_conv_fused weight tiles: 1 (default) global -> LDS DMA; 0 through staging registers */
-int lgen_set_igemm_variant(int v); /* 3 (default): 128x128 tile, 2 staging sets for pixels / 1 for weights; 0: 1 set; 1: 2 full sets; 2: 128x64 tiles */
+int lgen_set_igemm_variant(int v); /* 3 (default): 128x128 tile, 2 staging sets for pixels / 1 for weights; 0: 1 set; 2: 128x64 tiles; 1 (2 full sets, spilled) is refused */
 
 /* ---- lane streams (host-side plumbing for llamagen_amd/pipeline.py; no reference counterpart) ----
  * A HIP stream whose kernels may only occupy the CUs whose bit is set in mask_words (bit i of word i/32 = CU i;

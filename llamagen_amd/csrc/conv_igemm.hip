@@ -283,7 +283,11 @@ int lgen_vq_nt();  // vq_ops.hip
 // tuning knob (tools/): 0 = 128x128 tile, one staging set; 1 = 128x128, two staging sets; 2 = 128x64 tiles, two sets;
 // 3 = 128x128, two sets for the pixel tile only
 static int g_igemm_variant = 3;
-extern "C" int lgen_set_igemm_variant(int v) { g_igemm_variant = v; return 0; }
+extern "C" int lgen_set_igemm_variant(int v) {
+    if (v == 1) return LGEN_ERR_UNSUPPORTED;  // double-staged both operands: 144 B of scratch per lane, removed in round 3
+    g_igemm_variant = v;
+    return 0;
+}
 
 extern "C" int lgen_conv_igemm(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo, const float* bias,
                                const float* res, float* out, int B, int H, int W, int Cin, int Cout, int Npad, int ksize,
@@ -302,7 +306,6 @@ extern "C" int lgen_conv_igemm(const void* a_hi, const void* a_lo, const void* w
     hipStream_t st = (hipStream_t)stream;
     if (g_igemm_variant == 2 && Npad % 64 == 0) return launch_igemm<4, 2, 1, 1>(a, B, st);
     if (Npad % 128 == 0) {                                          // 128 px x 128 ch
-        if (g_igemm_variant == 1) return launch_igemm<4, 4, 2, 1>(a, B, st);
         if (g_igemm_variant == 3) return launch_igemm<4, 4, 2, 2>(a, B, st);
         return launch_igemm<4, 4, 2, 0>(a, B, st);
     }

@@ -185,19 +185,25 @@ __global__ __launch_bounds__(512) void gemm_normpre_kernel(GemmArgs a) {
     } else {
         // weights one whole n-group ahead in a second register set; every load below is unconditional inside its block, so
         // the compiler keeps counted waits (a load under `if` makes the join wait for vmcnt(0))
+        // (sched_barrier: without it the scheduler sinks these loads into the MFMA block below, reusing the registers the
+        // MFMAs free one by one -- which is MODE 1 again: the next group's weights would only be requested while this group
+        // computes, and every pass would start by waiting out a full memory latency)
         uint4 A1[CPW][NT];
         int p = 0;
         while (p + 2 < np) {
             np_load_w<MT, NT, CPW>(A1, wbase + (size_t)(p + 1) * gstride, wstride);
+            __builtin_amdgcn_sched_barrier(0);
             np_pass<D, MT, NT, EPI, CPW>(a, A0, B, red, w, KW, lane, (g0 + p) * NT, mt0, posr, []() {});
             if (!RED2) __syncthreads();
             np_load_w<MT, NT, CPW>(A0, wbase + (size_t)(p + 2) * gstride, wstride);
+            __builtin_amdgcn_sched_barrier(0);
             np_pass<D, MT, NT, EPI, CPW>(a, A1, B, red + rstride, w, KW, lane, (g0 + p + 1) * NT, mt0, posr, []() {});
             if (!RED2) __syncthreads();
             p += 2;
         }
         if (np - p == 2) {
             np_load_w<MT, NT, CPW>(A1, wbase + (size_t)(p + 1) * gstride, wstride);
+            __builtin_amdgcn_sched_barrier(0);
             np_pass<D, MT, NT, EPI, CPW>(a, A0, B, red, w, KW, lane, (g0 + p) * NT, mt0, posr, []() {});
             if (!RED2) __syncthreads();
             np_pass<D, MT, NT, EPI, CPW>(a, A1, B, red + rstride, w, KW, lane, (g0 + p + 1) * NT, mt0, posr, []() {});

@@ -195,8 +195,15 @@ __global__ __launch_bounds__((gemm_max_threads<MT, NT, NORM, EPI>())) void gemm_
     }
 }
 
+// ring-buffer shapes whose operand set does not fit 256 VGPRs (they would spill; csrc/gemm_skinny.usage): refused, not compiled
+template <int MT, int NT, int EPI, bool NORM>
+constexpr bool gemm_spills() { return NORM && (MT == 8 || (MT == 4 && NT == 4 && EPI == EPI_QKV)); }
+
 template <typename D, int MT, int NT, int EPI, bool NORM>
 static int launch(const GemmArgs& a, int kw, hipStream_t st) {
+    if constexpr (gemm_spills<MT, NT, EPI, NORM>()) {
+        return LGEN_ERR_UNSUPPORTED;
+    } else {
     constexpr int DEPTH = gemm_depth<MT, NT, NORM, EPI>();
     dim3 grid((a.N / 16) / NT, a.MTs / MT);
     size_t lds = kw > 1 ? (size_t)kw * NT * MT * 64 * sizeof(float4) : 0;
@@ -209,12 +216,13 @@ static int launch(const GemmArgs& a, int kw, hipStream_t st) {
     hipLaunchKernelGGL((gemm_kernel<D, MT, NT, EPI, NORM, DEPTH>), grid, dim3(64 * kw), lds, st, a);
     LGEN_CHECK_LAUNCH();
     return 0;
+    }
 }
 
 // the largest K-splitting wave count a (mt, nt) tile shape admits (register budget), for the host heuristics
 template <int EPI, bool NORM>
 static int max_kw_of(int mt, int nt) {
-#define LGEN_CASE(MT_, NT_) if (mt == MT_ && nt == NT_) return gemm_max_threads<MT_, NT_, NORM, EPI>() / 64;
+#define LGEN_CASE(MT_, NT_) if (mt == MT_ && nt == NT_) return gemm_spills<MT_, NT_, EPI, NORM>() ? 0 : gemm_max_threads<MT_, NT_, NORM, EPI>() / 64;
     LGEN_CASE(1, 1) LGEN_CASE(1, 2) LGEN_CASE(1, 4)
     LGEN_CASE(2, 1) LGEN_CASE(2, 2) LGEN_CASE(2, 4)
     LGEN_CASE(4, 1) LGEN_CASE(4, 2) LGEN_CASE(4, 4)

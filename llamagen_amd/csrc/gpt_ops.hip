@@ -215,10 +215,11 @@ extern "C" int lgen_rmsnorm(const void* hp, const void* weight, void* xnp, int M
     while (nw < 16 && nw * 4 < KCH) nw *= 2;  // ~4 chunks per wave, at most 8 (16 for very wide rows)
     if (nw * 16 < KCH) return LGEN_ERR_BAD_ARG;
     const bool wide = nw * 8 < KCH;
+    if (wide && dtype != LGEN_F32) return LGEN_ERR_UNSUPPORTED;  // 16-bit rows wider than 4096: 16 chunks per wave would spill (no registry model)
 #define LGEN_RMS(DT, C) hipLaunchKernelGGL((rmsnorm_kernel<DT, C>), dim3(MTs), dim3(64 * nw), 0, st, (const uint4*)hp, weight, \
                                            (uint4*)xnp, MTs, d, eps)
-    if (dtype == LGEN_BF16) { if (wide) LGEN_RMS(BF16, 16); else LGEN_RMS(BF16, 8); }
-    else if (dtype == LGEN_F16) { if (wide) LGEN_RMS(F16, 16); else LGEN_RMS(F16, 8); }
+    if (dtype == LGEN_BF16) LGEN_RMS(BF16, 8);
+    else if (dtype == LGEN_F16) LGEN_RMS(F16, 8);
     else if (dtype == LGEN_F32) { if (wide) LGEN_RMS(F32, 16); else LGEN_RMS(F32, 8); }
     else return LGEN_ERR_BAD_ARG;
 #undef LGEN_RMS

@@ -255,10 +255,11 @@ class DecodeEngine:
         ntiles = N // 16
         kch = K // self.kc
         if fused and kch % 8 == 0 and 3 <= kch // 8 <= 6:
-            # normpre kernel: every workgroup normalises its own rows of the panel, so halve the rows per
-            # workgroup and group n-tiles instead (measured best at MTs = 4: qkv (1,4,8), w1||w3 (2,4,8); at MTs = 8, i.e. two
-            # reference batches per chain, qkv (2,4,8): +18 % decode throughput of one 128-row chain, tools/exp_r2e.py)
-            mt = max(1, self.mt // (4 if kind == "qkv" and self.MTs <= 4 else 2))
+            # normpre kernel (persistent along N since round 3): every workgroup normalises its own rows of the panel once and
+            # walks `_passes` n-groups, so few rows per workgroup and 4 n-tiles per group.  Measured best (tools/gemm_sweep.py,
+            # GPT-L, profiles/r03_gemm_sweep.log): qkv (1, 4, 8) at every chain width (64 / 128 / 256 rows: 6.3 / 8.0 / 9.9 us with
+            # 1 / 2 / 3 passes), w1||w3 and lm_head (2, 4, 8) (8.5 / 10.7 / 12.6 us and 11.1 / 14.8 / 22.0 us)
+            mt = 1 if kind == "qkv" else max(1, self.mt // 2)
             nt = 4
             while ntiles % nt or (kind == "w13" and nt & 1 and nt > 1):
                 nt //= 2
@@ -284,7 +285,9 @@ class DecodeEngine:
         mt, nt, _ = tiles
         units = (N // 16 // nt) * (self.MTs // max(1, math.gcd(self.MTs, mt)))
         passes = max(1, -(-units // 256))
-        return passes, 1 if passes > 1 else 0
+        # weights of the next n-group in a second register set: no faster than reloading after the MFMAs (10.74 vs 10.76 us,
+        # w1||w3 at 128 rows) and bimodal inside the decode graph (73 / 63 img/s, tools/exp_r3c.py): off
+        return passes, 0
 
     # ---- launches -----------------------------------------------------------------------------
     def gemm(self, wp, xp, out, M, mts, N, K, epi, tiles, norm_w=None, ssq_out=None, sched=None):

@@ -177,20 +177,24 @@ def test_fused_rmsnorm_chain(dt, M, d, F, tiles):
     xn_ref = O.rms_norm(h_got, nw, 1e-5, dt)
     w13 = torch.stack([pack_weight(w1.to(dev)), pack_weight(w3.to(dev))], dim=1).flatten(0, 1).contiguous()
     gp = torch.zeros(F // kc, mts, 64, kc // 4, dtype=dt, device=dev)
-    L.check(lib.lgen_gemm(L.ptr(w13), L.ptr(hp), L.ptr(gp), M, mts, 2 * F, d, L.EPI_SWIGLU, code, mt, 2, kw, L.ptr(nw_d),
+    mt_n = min(mt, 4)  # fused-norm GEMMs exist up to 4 m-tiles per workgroup (mt = 8 would spill: refused by the library)
+    if mt == 8:
+        assert lib.lgen_gemm(L.ptr(w13), L.ptr(hp), L.ptr(gp), M, mts, 2 * F, d, L.EPI_SWIGLU, code, 8, 2, kw, L.ptr(nw_d),
+                             L.ptr(ssq), d // 16, 1e-5, 0, L.stream()) == L.ERR_UNSUPPORTED
+    L.check(lib.lgen_gemm(L.ptr(w13), L.ptr(hp), L.ptr(gp), M, mts, 2 * F, d, L.EPI_SWIGLU, code, mt_n, 2, kw, L.ptr(nw_d),
                           L.ptr(ssq), d // 16, 1e-5, 0, L.stream()), "norm+swiglu")
     a1, a3 = O.linear(xn_ref, w1.float(), dt), O.linear(xn_ref, w3.float(), dt)
     _close(unpack_act(gp, M), O._rnd(O._rnd(torch.nn.functional.silu(a1), dt) * a3, dt), dt, "norm+swiglu", frac_ulp1=0.08, ulps=3)
     rows = torch.zeros(R, 256, dtype=dt, device=dev)
     woutp = pack_weight(wout.to(dev))
-    L.check(lib.lgen_gemm(L.ptr(woutp), L.ptr(hp), L.ptr(rows), M, mts, 256, d, L.EPI_ROWS, code, mt, nt, kw, L.ptr(nw_d),
+    L.check(lib.lgen_gemm(L.ptr(woutp), L.ptr(hp), L.ptr(rows), M, mts, 256, d, L.EPI_ROWS, code, mt_n, nt, kw, L.ptr(nw_d),
                           L.ptr(ssq), d // 16, 1e-5, 0, L.stream()), "norm+rows")
     _close(rows[:M], O.linear(xn_ref, wout.float(), dt), dt, "norm+rows", frac_ulp1=0.05)
     # 3. ssq_pack / embed produce the same statistic (their own d/16 partials)
     ssq2 = torch.full((R, L.SSQ_STRIDE), float("nan"), device=dev)
     L.check(lib.lgen_ssq_pack(L.ptr(hp), L.ptr(ssq2), mts, d, code, L.stream()), "ssq_pack")
     np.testing.assert_allclose(ssq2[:M, :d // 16].sum(1).cpu().numpy(), (h_got.double() ** 2).sum(-1).float().numpy(), rtol=1e-5)
-    L.check(lib.lgen_gemm(L.ptr(woutp), L.ptr(hp), L.ptr(rows), M, mts, 256, d, L.EPI_ROWS, code, mt, nt, kw, L.ptr(nw_d),
+    L.check(lib.lgen_gemm(L.ptr(woutp), L.ptr(hp), L.ptr(rows), M, mts, 256, d, L.EPI_ROWS, code, mt_n, nt, kw, L.ptr(nw_d),
                           L.ptr(ssq2), d // 16, 1e-5, 0, L.stream()), "norm+rows (ssq_pack parts)")
     _close(rows[:M], O.linear(xn_ref, wout.float(), dt), dt, "norm+rows 2", frac_ulp1=0.05)
     table = _rand((50, d), dt, 38)

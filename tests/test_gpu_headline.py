@@ -172,7 +172,8 @@ def test_config2_gptl_bf16_two_batches_per_chain_logits_vs_oracle():
     recs, m = _teacher_forced(case, B, 4.0, early=3, late=[299], cond=cond)
     e = m._engine
     assert e.fuse_norm and e.MTs == 8 and e.S8 == 584
-    assert e._tiles("qkv", 3 * e.d, e.d) == (2, 4, 8) and e._tiles("w13", 2 * e.F, e.d) == (2, 4, 8)  # what bench.py replays
+    assert e._tiles("qkv", 3 * e.d, e.d) == (1, 4, 8) and e._tiles("w13", 2 * e.F, e.d) == (2, 4, 8)
+    assert e._passes("qkv", 3 * e.d, (1, 4, 8)) == (2, 0) and e._passes("w13", 2 * e.F, (2, 4, 8)) == (2, 0)
     _check("config2_gptl_b128", recs)
 
 
@@ -187,7 +188,9 @@ def test_config2_gptl_bf16_four_batches_per_chain_logits_vs_oracle():
     recs, m = _teacher_forced(case, B, 4.0, early=2, late=[299], cond=cond)
     e = m._engine
     assert e.fuse_norm and e.MTs == 16 and e.S8 == 584
-    assert e._passes("w13", 2 * e.F, e._tiles("w13", 2 * e.F, e.d))[0] > 1   # the persistent form is what ran
+    assert e._tiles("qkv", 3 * e.d, e.d) == (1, 4, 8) and e._tiles("w13", 2 * e.F, e.d) == (2, 4, 8)  # what bench.py replays
+    assert e._passes("qkv", 3 * e.d, (1, 4, 8)) == (3, 0) and e._passes("w13", 2 * e.F, (2, 4, 8)) == (3, 0)
+    assert e._passes("head", e.V, e._tiles("head", e.V, e.d)) == (8, 0)   # the persistent form is what ran
     _check("config2_gptl_b256", recs)
 
 

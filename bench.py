@@ -133,18 +133,21 @@ def measure_gemms(gpt, reps=5):
     e.ssq_parts = d // 16
     e.state.zero_()
     nw = lambda w: w if e.fuse_norm else None
+    sq, s13, sh = e._passes("qkv", 3 * d, tq), e._passes("w13", 2 * F, t13), e._passes("head", V, th)   # the decode graph's schedules
 
     def qkv():
         for w in e.layers:
+            if e.fuse_norm and sq[0] > 1:
+                L.check(lib.lgen_gemm_schedule_hint(sq[0], sq[1]), "hint")
             L.check(lib.lgen_gemm_qkv_rope(L.ptr(w["wqkv"]), L.ptr(e.hp), L.ptr(e.qbuf), L.ptr(e.k_cache[0]), L.ptr(e.v_cache[0]),
                                            L.ptr(e.freqs_cis), L.ptr(e.state), M, mts, d, H, hd, hdp, S8, e.kvs, dt, tq[0], tq[1], tq[2],
                                            L.ptr(nw(w["an"])), L.ptr(e.ssq if e.fuse_norm else None), e.ssq_parts, e.eps, L.stream()), "qkv")
     kinds = {
         "wqkv": (qkv, 3 * d * d),
         "wo": (lambda: [e.gemm(w["wo"], e.ap, e.hp, M, mts, d, d, L.EPI_RES, to, ssq_out=e.ssq if e.fuse_norm else None) for w in e.layers], d * d),
-        "w13": (lambda: [e.gemm(w["w13"], e.hp, e.gp, M, mts, 2 * F, d, L.EPI_SWIGLU, t13, norm_w=nw(w["fn"])) for w in e.layers], 2 * F * d),
+        "w13": (lambda: [e.gemm(w["w13"], e.hp, e.gp, M, mts, 2 * F, d, L.EPI_SWIGLU, t13, norm_w=nw(w["fn"]), sched=s13) for w in e.layers], 2 * F * d),
         "w2": (lambda: [e.gemm(w["w2"], e.gp, e.hp, M, mts, d, F, L.EPI_RES, t2, ssq_out=e.ssq if e.fuse_norm else None) for w in e.layers], F * d),
-        "lm_head": (lambda: [e.gemm(e.out_w, e.hp, e.logits, M, mts, V, d, L.EPI_ROWS, th, norm_w=nw(e.norm_w)) for _ in range(4)], V * d),
+        "lm_head": (lambda: [e.gemm(e.out_w, e.hp, e.logits, M, mts, V, d, L.EPI_ROWS, th, norm_w=nw(e.norm_w), sched=sh) for _ in range(4)], V * d),
     }
     esz = 2 if e.dtype == torch.bfloat16 else 4
     stream = torch.cuda.Stream()
@@ -167,6 +170,8 @@ def measure_gemms(gpt, reps=5):
                 stream.synchronize()
                 best = min(best, e0.elapsed_time(e1) * 1e3 / (reps * launches))
             out[kind] = (best, nparam * esz)
+    out["_schedule"] = {"tiles": {"wqkv": tq, "wo": to, "w13": t13, "w2": t2, "lm_head": th},
+                        "passes": {"wqkv": sq[0], "w13": s13[0], "lm_head": sh[0]}}
     return out
 
 
@@ -601,6 +606,7 @@ def main():
                                "algorithmic_bytes_per_launch": int(nbytes / launches),
                                "launch_us_by_position": per_pos}
             gm = measure_gemms(pipe.lanes[0].gpt)
+            gsched = gm.pop("_schedule")
             nlay = gpt.config.n_layer
             tot_us = sum(us * (1 if k == "lm_head" else nlay) for k, (us, _) in gm.items())
             tot_b = sum(b * (1 if k == "lm_head" else nlay) for k, (_, b) in gm.items())
@@ -608,6 +614,7 @@ def main():
                                     "achieved": round(tot_b / tot_us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                     "frac": round(tot_b / tot_us / 1e3 / HBM_PEAK_GBS, 4),
                                     "weight_bytes_per_step": int(tot_b), "us_per_step": round(tot_us, 1),
+                                    "us_per_step_per_128_rows": round(tot_us * 128 / rows, 1), "schedule": gsched,
                                     "launches_per_step": pipe.lanes[0].gpt._engine.launches_per_step(),
                                     "per_launch": {k: {"us": round(us, 2), "weight_bytes": int(b), "GB/s": round(b / us / 1e3, 1),
                                                        "fetch_over_algorithmic": (pmc.get("gemm", {}).get(k) or {}).get("fetch_over_algorithmic")}

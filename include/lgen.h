@@ -205,20 +205,23 @@ int lgen_conv_igemm(const void* a_hi, const void* a_lo, const void* w_hi, const 
  * (gn_coef [B][Cin][2] = (scale, shift) from lgen_gn_finalize, or NULL), the activation and the hi/lo bf16 split done
  * on the tile load (x is read once, as fp32 NHWC [B][H>>upsample][W>>upsample][Cin]), the 3x3 taps served from an
  * LDS-resident halo tile, and -- stats_partial != NULL -- the next GroupNorm's per-(8x16 tile, 4-channel quad)
- * (sum, sumsq) of the stored output written to stats_partial [B][(H/8)*(W/16)][Npad/4][2].  upsample = 1 folds
+ * (sum, M2) of the stored output written to stats_partial [B][(H/8)*ceil(W/16)][Npad/4][2].  upsample = 1 folds
  * F.interpolate(2.0, nearest).  w_frag: hi/lo bf16 weights in MFMA fragment order
- * [Npad/BN][Cin/32][ksize^2][2][BN/16][64 lanes][8], BN = lgen_conv_fused_bn(Cout).  Needs H % 8 == 0, W % 16 == 0,
- * Cin % 32 == 0 (other shapes: lgen_gn_stats + lgen_gn_swish_split + lgen_conv_igemm). */
+ * [Npad/BN][Cin/32][ksize^2][2][BN/16][64 lanes][8], BN = lgen_conv_fused_bn(Cout).  Needs H % 8 == 0 and Cin % 32 == 0; W is
+ * free (tiles are 8 x 16 pixels, the columns past W of the last tile column are computed and dropped: 24-wide maps of a 384 px
+ * decode).  Other shapes: lgen_gn_stats + lgen_gn_swish_split + lgen_conv_igemm. */
 int lgen_conv_fused_bn(int Cout);
 int lgen_conv_fused(const float* x_nhwc, const float* gn_coef, int swish, const void* w_frag, const float* bias,
                     const float* res, float* out, float* stats_partial, int B, int H, int W, int Cin, int Cout, int Npad,
                     int ksize, int upsample, int out_nchw, void* stream);
 
 /* GroupNorm(32, C, eps) statistics -> per-channel (scale, shift) = (rstd*gamma, beta - rstd*gamma*mean), coef [B][C][2].
- * Source: partial != NULL: the tile partials of lgen_conv_fused ([B][ntiles][quad_stride][2], combined in fp64 in a
- * fixed order; hw = pixels per image); else stats [B][32][2] = (mean, rstd) from lgen_gn_stats. */
+ * Source: partial != NULL: the tile partials of lgen_conv_fused ([B][ntiles][quad_stride][2] = (sum, M2 about the partial's
+ * own mean), combined in fp64 in a fixed order with the pairwise update of Chan et al.; hw = pixels per image, width = W of the
+ * map the partials tile (ABI v6: a partial of the last tile column covers W - 16 * (tiles_x - 1) columns)); else stats
+ * [B][32][2] = (mean, rstd) from lgen_gn_stats (width ignored). */
 int lgen_gn_finalize(const float* partial, const float* stats, const float* gamma, const float* beta, float* coef, int B,
-                     int C, int ntiles, int quad_stride, int hw, float eps, void* stream);
+                     int C, int ntiles, int quad_stride, int hw, int width, float eps, void* stream);
 
 /* ---- post-processing of decoded samples (autoregressive/sample/sample_c2i_ddp.py:141-143) ------------- */
 

@@ -62,7 +62,7 @@ SIGNATURES = {
     "lgen_softmax_split": [_P, _P, _P, _I, _I, _I, _P],
     "lgen_conv_fused_bn": [_I],
     "lgen_conv_fused": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
-    "lgen_gn_finalize": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
+    "lgen_gn_finalize": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
     "lgen_conv_igemm": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _c.c_longlong, _F, _P],
 }
 

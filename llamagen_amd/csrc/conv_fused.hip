@@ -13,7 +13,7 @@
 //     registers and kept in LDS as (hi, lo) bf16 for all nine taps: staging traffic per tap is the weight tile only;
 //   * the 3-pass split-bf16 product (hi*hi + hi*lo + lo*hi, fp32 accumulate on v_mfma_f32_16x16x32_bf16) is
 //     unchanged: <= 1.3e-4 abs against the fp32 reference decoder (single-pass bf16: 9e-2);
-//   * the epilogue reduces per-(tile, 4-channel quad) sums of the stored fp32 values, so the consumer's
+//   * the epilogue reduces per-(tile, 4-channel quad) (sum, M2) of the stored fp32 values, so the consumer's
 //     GroupNorm needs no pass over the activation (lgen_gn_finalize turns the partials into per-channel
 //     (scale, shift) pairs).
 //
@@ -293,11 +293,15 @@ __global__ __launch_bounds__(64 * NWV, NWV / 2) void conv_fused_kernel(ConvFArgs
 #undef CF_STEP
 #undef CF_GLOAD_HALO
 
-    // epilogue: lane holds channels n = n0 + g*4 + {0..3} of pixel (y0 + row, x0 + fr)
+    // epilogue: lane holds channels n = n0 + g*4 + {0..3} of pixel (y0 + row, x0 + fr).  W need not be a multiple of the
+    // 16-pixel tile width (24 x 24 maps of a 384 px decode): columns >= W of the last tile column are computed and dropped.
     const size_t HW = (size_t)a.H * a.W;
     float* outb = a.out + (size_t)b * HW * a.Cout;
     const float* resb = a.res ? a.res + (size_t)b * HW * a.Cout : nullptr;
     float* red = (float*)smem;  // [WMW][BN/4][2] after the main loop (all LDS reads are behind the last barrier)
+    const int cntx = (a.W - x0) < TW ? (a.W - x0) : TW;   // valid columns of this tile (uniform over the workgroup)
+    const bool inx = fr < cntx;
+    const int xs = x0 + (inx ? fr : cntx - 1);             // clamped column: loads of dropped pixels stay inside the image
     // All residual loads of the wave's tiles first (the halo / fragment registers are dead here): inside the store loop below each
     // load would sit behind the previous tile's store (`out` and `res` may alias as far as the compiler knows), i.e. JN x JM
     // dependent memory round trips per tile -- measured as 10 % of the kernel.
@@ -308,8 +312,9 @@ __global__ __launch_bounds__(64 * NWV, NWV / 2) void conv_fused_kernel(ConvFArgs
         for (int j = 0; j < JN; ++j)
 #pragma unroll
             for (int i = 0; i < JM; ++i)
-                rres[j][i] = *(const float4*)(resb + ((size_t)(y0 + wm * JM + i) * a.W + x0 + fr) * a.Cout + nb * BN + (wn * JN + j) * 16 + fg * 4);
+                rres[j][i] = *(const float4*)(resb + ((size_t)(y0 + wm * JM + i) * a.W + xs) * a.Cout + nb * BN + (wn * JN + j) * 16 + fg * 4);
     }
+    const float nsub = 4.0f * JM * cntx;   // values per (lane group of 16 pixels x JM rows x 4 channels) statistic
 #pragma unroll
     for (int j = 0; j < JN; ++j) {
         const int nl = (wn * JN + j) * 16 + fg * 4;
@@ -324,11 +329,11 @@ __global__ __launch_bounds__(64 * NWV, NWV / 2) void conv_fused_kernel(ConvFArgs
                 for (int e = 0; e < 4; ++e) bs[e] = n + e < a.Cout ? a.bias[n + e] : 0.f;
             }
         }
-        float ssum = 0.f, sq = 0.f;
+        float vals[JM][4];
 #pragma unroll
         for (int i = 0; i < JM; ++i) {
-            const int y = y0 + wm * JM + i, x = x0 + fr;
-            const size_t p = (size_t)y * a.W + x;
+            const int y = y0 + wm * JM + i;
+            const size_t p = (size_t)y * a.W + xs;
             float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = acc[j][i][e] + bs[e];
@@ -338,43 +343,59 @@ __global__ __launch_bounds__(64 * NWV, NWV / 2) void conv_fused_kernel(ConvFArgs
                     const float4 r = res_fast ? rres[j][i] : *(const float4*)(resb + o);
                     v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
                 }
-                *(float4*)(outb + o) = make_float4(v[0], v[1], v[2], v[3]);
+                if (inx) *(float4*)(outb + o) = make_float4(v[0], v[1], v[2], v[3]);
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     if (n + e >= a.Cout) { v[e] = 0.f; continue; }
                     const size_t o = a.out_nchw ? (size_t)(n + e) * HW + p : p * a.Cout + n + e;
                     if (resb) v[e] += resb[o];
-                    outb[o] = v[e];
+                    if (inx) outb[o] = v[e];
                 }
             }
-            ssum += (v[0] + v[1]) + (v[2] + v[3]);
-            sq += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-        }
-        if (a.part) {  // fixed-order reduction over the 16 pixels of the lane group, then over wm through LDS
 #pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
-                ssum += __shfl_xor(ssum, o, 64);
-                sq += __shfl_xor(sq, o, 64);
+            for (int e = 0; e < 4; ++e) vals[i][e] = v[e];
+        }
+        if (a.part) {
+            // Statistics of the stored values for the NEXT GroupNorm as (sum, M2 = sum of squared deviations from the local mean):
+            // first over the wave's 16 pixels x JM rows x 4 channels (fixed-order shuffles), then over wm through LDS with the
+            // pairwise update of Chan et al.  (A plain sum of squares loses the variance to cancellation when |mean| >> std.)
+            float ssum = 0.f;
+#pragma unroll
+            for (int i = 0; i < JM; ++i) ssum += inx ? (vals[i][0] + vals[i][1]) + (vals[i][2] + vals[i][3]) : 0.f;
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) ssum += __shfl_xor(ssum, o, 64);
+            const float mean = ssum / nsub;
+            float m2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < JM; ++i) {
+                const float d0 = vals[i][0] - mean, d1 = vals[i][1] - mean, d2 = vals[i][2] - mean, d3 = vals[i][3] - mean;
+                m2 += inx ? (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3) : 0.f;
             }
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) m2 += __shfl_xor(m2, o, 64);
             if (fr == 0) {
                 red[(wm * (BN / 4) + (nl >> 2)) * 2 + 0] = ssum;
-                red[(wm * (BN / 4) + (nl >> 2)) * 2 + 1] = sq;
+                red[(wm * (BN / 4) + (nl >> 2)) * 2 + 1] = m2;
             }
         }
     }
     if (a.part) {
         __syncthreads();
         if (t < BN / 4) {
-            float s = 0.f, q = 0.f;
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < WMW; ++w) s += red[(w * (BN / 4) + t) * 2 + 0];
+            const float mean = s / (nsub * WMW);
+            float m2 = 0.f;
 #pragma unroll
             for (int w = 0; w < WMW; ++w) {
-                s += red[(w * (BN / 4) + t) * 2 + 0];
-                q += red[(w * (BN / 4) + t) * 2 + 1];
+                const float dm = red[(w * (BN / 4) + t) * 2 + 0] / nsub - mean;
+                m2 += red[(w * (BN / 4) + t) * 2 + 1] + nsub * dm * dm;
             }
             float* dst = a.part + (((size_t)b * a.ntiles + tile) * (a.Npad / 4) + nb * (BN / 4) + t) * 2;
             dst[0] = s;
-            dst[1] = q;
+            dst[1] = m2;
         }
     }
 }
@@ -400,14 +421,14 @@ extern "C" int lgen_conv_fused_bn(int Cout) { return Cout >= 128 ? 128 : (Cout >
 extern "C" int lgen_conv_fused(const float* x_nhwc, const float* gn_coef, int swish, const void* w_frag, const float* bias,
                                const float* res, float* out, float* stats_partial, int B, int H, int W, int Cin, int Cout,
                                int Npad, int ksize, int upsample, int out_nchw, void* stream) {
-    if ((ksize != 1 && ksize != 3) || Cin % 32 || H % 8 || W % 16 || Npad < Cout || (upsample && ((H | W) & 1)) ||
+    if ((ksize != 1 && ksize != 3) || Cin % 32 || H % 8 || W < 1 || Npad < Cout || (upsample && ((H | W) & 1)) ||
         upsample < 0 || upsample > 1)
         return LGEN_ERR_BAD_ARG;
     if (B == 0) return 0;
     const int bn = lgen_conv_fused_bn(Cout);
     if (Npad % bn) return LGEN_ERR_BAD_ARG;
     ConvFArgs a{x_nhwc, (const float2*)gn_coef, (const uint4*)w_frag, bias, res, out, stats_partial,
-                H, W, Cin, Cout, Npad, upsample, swish ? 1 : 0, out_nchw, W / 16, (H / 8) * (W / 16)};
+                H, W, Cin, Cout, Npad, upsample, swish ? 1 : 0, out_nchw, (W + 15) / 16, (H / 8) * ((W + 15) / 16)};
     hipStream_t st = (hipStream_t)stream;
     // 4 waves x (64 ch x 64 px).  Measured alternative: 8 waves x (32 ch x 64 px) per workgroup (4 waves per SIMD instead of 2)
     // runs at the same speed (2.54 vs 2.57 ms, 16 x 384 px, 128 -> 128): the kernel is not short of waves to hide latency.
@@ -422,32 +443,42 @@ extern "C" int lgen_conv_fused(const float* x_nhwc, const float* gn_coef, int sw
 // ---------------------------------------------------------------------------------------------
 // GroupNorm statistics -> per-channel (scale, shift): coef[b][c] = (rstd*gamma_c, beta_c - rstd*gamma_c*mean)
 // (vq_model.py:359-362, eps inside the sqrt, biased variance).  Input is either the per-tile partials written by
-// lgen_conv_fused (ntiles > 0: part[b][tile][C/4][2], fp32, combined here in fp64 in a fixed order) or finished
+// lgen_conv_fused (ntiles > 0: part[b][tile][C/4][2] = (sum, M2), fp32, combined here in fp64 in a fixed order) or finished
 // statistics stats[b][32][2] = (mean, rstd) from lgen_gn_stats (ntiles == 0).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ part, const float* __restrict__ stats,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          float2* __restrict__ coef, int ntiles, int C, int Cq_stride,
-                                                         double count, float eps) {
+                                                         double count, float eps, int width) {
     const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
     const int gs = C >> 5;
     float mean, rstd;
     if (ntiles > 0) {
+        // partials are (sum, M2 about the partial's own mean) over n_i = 4 channels x 8 rows x (valid columns of the tile) values:
+        // total mean first, then M2 = sum_i [M2_i + n_i (mean_i - mean)^2] (Chan et al.), in fp64, fixed order
         const int qpg = gs >> 2;  // 4-channel quads per group
-        double S = 0.0, Q = 0.0;
+        const int tiles_x = (width + 15) >> 4;
+        double S = 0.0;
+        for (int i = lane; i < ntiles * qpg; i += 64) {
+            const int tile = i / qpg, qq = i - tile * qpg;
+            S += (double)part[(((size_t)b * ntiles + tile) * Cq_stride + g * qpg + qq) * 2];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) S += __shfl_xor(S, o, 64);
+        const double m = S / count;
+        double Q = 0.0;
         for (int i = lane; i < ntiles * qpg; i += 64) {
             const int tile = i / qpg, qq = i - tile * qpg;
             const float* p = part + (((size_t)b * ntiles + tile) * Cq_stride + g * qpg + qq) * 2;
-            S += (double)p[0];
-            Q += (double)p[1];
+            const int tx = tile % tiles_x;
+            const int cnt = width - 16 * tx < 16 ? width - 16 * tx : 16;
+            const double n_i = 32.0 * cnt;
+            const double dm = (double)p[0] / n_i - m;
+            Q += (double)p[1] + n_i * dm * dm;
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            S += __shfl_xor(S, o, 64);
-            Q += __shfl_xor(Q, o, 64);
-        }
-        const double m = S / count;
-        double var = Q / count - m * m;
+        for (int o = 32; o > 0; o >>= 1) Q += __shfl_xor(Q, o, 64);
+        double var = Q / count;
         var = var < 0.0 ? 0.0 : var;
         mean = (float)m;
         rstd = (float)(1.0 / sqrt(var + (double)eps));
@@ -462,11 +493,11 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
 }
 
 extern "C" int lgen_gn_finalize(const float* partial, const float* stats, const float* gamma, const float* beta, float* coef,
-                                int B, int C, int ntiles, int quad_stride, int hw, float eps, void* stream) {
-    if (C % 128 || (!partial && !stats) || (partial && ntiles < 1)) return LGEN_ERR_BAD_ARG;
+                                int B, int C, int ntiles, int quad_stride, int hw, int width, float eps, void* stream) {
+    if (C % 128 || (!partial && !stats) || (partial && (ntiles < 1 || width < 1 || ntiles % ((width + 15) / 16)))) return LGEN_ERR_BAD_ARG;
     if (B == 0) return 0;
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(32, B), dim3(64), 0, (hipStream_t)stream, partial, stats, gamma, beta,
-                       (float2*)coef, partial ? ntiles : 0, C, quad_stride, (double)hw * (C / 32), eps);
+                       (float2*)coef, partial ? ntiles : 0, C, quad_stride, (double)hw * (C / 32), eps, width);
     LGEN_CHECK_LAUNCH();
     return 0;
 }

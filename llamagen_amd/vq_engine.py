@@ -56,12 +56,12 @@ class _GNW:
 
 
 class _Act:
-    """An NHWC fp32 activation plus, when a fused conv produced it, the per-tile (sum, sumsq) partials of its values
-    (the next GroupNorm's statistics without another pass over the tensor)."""
-    __slots__ = ("t", "part", "ntiles", "qstride")
+    """An NHWC fp32 activation plus, when a fused conv produced it, the per-tile (sum, M2) partials of its values
+    (the next GroupNorm's statistics without another pass over the tensor) and the width of the map they tile."""
+    __slots__ = ("t", "part", "ntiles", "qstride", "width")
 
-    def __init__(self, t, part=None, ntiles=0, qstride=0):
-        self.t, self.part, self.ntiles, self.qstride = t, part, ntiles, qstride
+    def __init__(self, t, part=None, ntiles=0, qstride=0, width=0):
+        self.t, self.part, self.ntiles, self.qstride, self.width = t, part, ntiles, qstride, width
 
 
 class VQEngine:
@@ -144,7 +144,7 @@ class VQEngine:
     # ---- fused path (lgen_conv_fused): GroupNorm-apply / swish / split on the tile load, statistics in the epilogue --------
     @staticmethod
     def _fusable(H, W):
-        return H % 8 == 0 and W % 16 == 0
+        return H % 8 == 0 and W >= 8   # tiles are 8 x 16 pixels; a last tile column may be partly outside the map (24-wide maps)
 
     def _coef(self, x: "_Act", gn: _GNW, B, hw, C):
         """Per-channel (scale, shift) of GroupNorm `gn` on activation x: from the producer's tile partials when it has them,
@@ -152,10 +152,10 @@ class VQEngine:
         coef = torch.empty(B * C * 2, dtype=torch.float32, device=self.dev)
         if x.part is not None:
             L.check(self.lib.lgen_gn_finalize(L.ptr(x.part), 0, L.ptr(gn.gamma), L.ptr(gn.beta), L.ptr(coef), B, C, x.ntiles,
-                                              x.qstride, hw, gn.eps, L.stream()), "gn_finalize")
+                                              x.qstride, hw, x.width, gn.eps, L.stream()), "gn_finalize")
         else:
             st = self._stats(x.t, B, hw, C, gn.eps)
-            L.check(self.lib.lgen_gn_finalize(0, L.ptr(st), L.ptr(gn.gamma), L.ptr(gn.beta), L.ptr(coef), B, C, 0, 0, hw, gn.eps,
+            L.check(self.lib.lgen_gn_finalize(0, L.ptr(st), L.ptr(gn.gamma), L.ptr(gn.beta), L.ptr(coef), B, C, 0, 0, hw, 0, gn.eps,
                                               L.stream()), "gn_finalize")
         return coef
 
@@ -163,13 +163,13 @@ class VQEngine:
                want_part=True) -> "_Act":
         """H, W = OUTPUT size.  x.t is fp32 NHWC [B][H>>ups][W>>ups][cin]."""
         out = torch.empty(B * H * W * cw.cout, dtype=torch.float32, device=self.dev)
-        ntiles = (H // 8) * (W // 16)
+        ntiles = (H // 8) * ((W + 15) // 16)
         part = torch.empty(B * ntiles * (cw.fnpad // 4) * 2, dtype=torch.float32, device=self.dev) if want_part else None
         L.check(self.lib.lgen_conv_fused(L.ptr(x.t), L.ptr(coef), 1 if swish else 0, L.ptr(cw.frag), L.ptr(cw.bias),
                                          L.ptr(res.t if isinstance(res, _Act) else res), L.ptr(out), L.ptr(part), B, H, W, cw.cin,
                                          cw.cout, cw.fnpad, cw.k, 1 if upsample else 0, 1 if out_nchw else 0, L.stream()),
                 "conv_fused")
-        return _Act(out, part, ntiles, cw.fnpad // 4)
+        return _Act(out, part, ntiles, cw.fnpad // 4, W)
 
     def _res_fused(self, x: "_Act", p, B, H, W) -> "_Act":
         hw, cin = H * W, p["c1"].cin
@@ -197,13 +197,21 @@ class VQEngine:
         return self._conv(self._split(h, B, hw, cmid, p["n2"], True), p["c2"], B, H, W, res=skip)
 
     def _attn(self, x, p, B, H, W):
-        if isinstance(x, _Act):
+        fused = isinstance(x, _Act) and self.fused and self._fusable(H, W)
+        if isinstance(x, _Act) and not fused:
             return _Act(self._attn(x.t, p, B, H, W))
         hw, c = H * W, p["q"].cin
-        hn = self._split(x, B, hw, c, p["n"], False)
-        q = self._conv(hn, p["q"], B, H, W)
-        k = self._conv(hn, p["k"], B, H, W)
-        v = self._conv(hn, p["v"], B, H, W)
+        if fused:  # GroupNorm-apply on the tile load of the three 1x1 convs (no activation, vq_model.py:330-334)
+            coef = self._coef(x, p["n"], B, hw, c)
+            xa, x = x, x.t
+            q = self._convf(xa, p["q"], B, H, W, coef=coef, want_part=False).t
+            k = self._convf(xa, p["k"], B, H, W, coef=coef, want_part=False).t
+            v = self._convf(xa, p["v"], B, H, W, coef=coef, want_part=False).t
+        else:
+            hn = self._split(x, B, hw, c, p["n"], False)
+            q = self._conv(hn, p["q"], B, H, W)
+            k = self._conv(hn, p["k"], B, H, W)
+            v = self._conv(hn, p["v"], B, H, W)
         blk = 128 if hw % 128 == 0 else (64 if hw % 64 == 0 else 16)
         npad = (hw + blk - 1) // blk * blk
         ld = (hw + 31) // 32 * 32
@@ -218,6 +226,8 @@ class VQEngine:
         L.check(self.lib.lgen_split_t(L.ptr(v), L.ptr(vh), L.ptr(vl), B, hw, c, ld, L.stream()), "split_t")
         cblk = 128 if c % 128 == 0 else (64 if c % 64 == 0 else 16)
         o = self._gemm_nt((ph, pl), (vh, vl), B, hw, c, ld, (c + cblk - 1) // cblk * cblk, 1.0)
+        if fused:  # proj_out + skip, with the statistics of the result for the next block's norm1
+            return self._convf(_Act(o), p["p"], B, H, W, res=xa)
         return self._conv(self._split(o, B, hw, c), p["p"], B, H, W, res=x)
 
     # ---- public ----------------------------------------------------------------------------------

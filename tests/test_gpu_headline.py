@@ -237,11 +237,20 @@ def test_fused_norm_gemm_passes_bit_identical(M):
         torch.cuda.synchronize()
         return q, kc[:, :, pos].clone(), vc[:, :, pos].clone(), gp, rows
 
-    xn = O.rms_norm(x.float(), nw, 1e-5, dt)
+    # The kernel's own normalised activations, read back through an identity weight matrix (exact: one product per output).
+    # They may differ from the oracle's by 1 bf16 ulp in a few elements of a row -- legitimately: the row scale 1/rms comes from
+    # a differently ordered fp32 sum, a 1-ulp change of it moves x * scale across a rounding boundary for ALL elements of the row
+    # that share a bf16 mantissa (128 distinct ones; tools/diag_m256.py: 12 elements of row 238 at 256 rows) -- so the GEMM +
+    # epilogue below are held to the oracle's nn.Linear on the activations the kernel really used.
+    eyep = pack_weight(torch.eye(d, dtype=dt).to(dev))
+    xrows = torch.zeros(mts * 16, d, dtype=dt, device=dev)
+    L.check(lib.lgen_gemm(L.ptr(eyep), L.ptr(xp), L.ptr(xrows), M, mts, d, d, L.EPI_ROWS, L.BF16, 2, 4, 8, L.ptr(nw_d), L.ptr(ssq),
+                          d // 16, 1e-5, 0, L.stream()), "norm + identity")
+    xn_ref = O.rms_norm(x.float(), nw, 1e-5, dt)
+    xn = xrows[:M].float().cpu()
+    dx = (xn - xn_ref).abs()
+    assert (dx > 0).float().mean().item() < 1e-3 and (dx <= xn_ref.abs() * 2.0 ** -7 + 1e-30).all(), ((dx > 0).sum().item(), dx.max().item())
     ref_rows = O.linear(xn, wh.float(), dt)
-    a1, a3 = O.linear(xn, w1.float(), dt), O.linear(xn, w3.float(), dt)
-    ref_gp = O._rnd(O._rnd(torch.nn.functional.silu(a1), dt) * a3, dt)
-    ref_v = O.linear(xn, wq.float(), dt)[:, 2 * d:].reshape(M, H, hd)
     first = None
     for tile in [(2, 4), (1, 4), (2, 2), (4, 2)]:  # qkv (4, 2) has no multi-pass form (register budget): falls back to one pass
         if tile[0] > mts:
@@ -258,9 +267,9 @@ def test_fused_norm_gemm_passes_bit_identical(M):
             assert torch.equal(a, b), (tile, "vs first tile", name, (a.float() - b.float()).abs().max().item())
         q, k, v, gp, rows = base
         assert torch.isfinite(rows[:M].float()).all() and torch.isfinite(gp.float()).all()
-        _close(rows[:M], ref_rows, dt, f"norm+lm_head {tile}", frac_ulp1=0.05, ulps=2)
+        _close(rows[:M], ref_rows, dt, f"norm+lm_head {tile}", frac_ulp1=0.05)
         _close(unpack_act(gp, M), ref_gp, dt, f"norm+swiglu {tile}", frac_ulp1=0.08, ulps=3)
-        _close(v, ref_v, dt, f"v row {tile}", frac_ulp1=0.05, ulps=2)
+        _close(v, ref_v, dt, f"v row {tile}", frac_ulp1=0.05)
 
 
 @pytest.mark.parametrize("d,H,M,mt", [(1024, 16, 64, 1), (1280, 20, 64, 1), (1536, 24, 64, 1), (768, 12, 64, 1),

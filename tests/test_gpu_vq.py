@@ -286,6 +286,9 @@ def test_extract_codes_flip_augmentation():
     (2, 8, 16, 128, 128, 3, 0, 1, 0, 1), (1, 16, 32, 256, 128, 3, 0, 0, 0, 1), (2, 16, 16, 128, 128, 3, 1, 0, 0, 0),
     (1, 8, 32, 256, 128, 1, 0, 0, 0, 0), (2, 16, 16, 128, 3, 3, 0, 0, 1, 1), (1, 48, 48, 512, 256, 3, 0, 1, 0, 1),
     (1, 24, 16, 64, 256, 3, 0, 0, 0, 0),
+    # W not a multiple of the 16-pixel tile width (round 3): the 24 x 24 level of a 384 px decode, a 1x1 conv, an upsampled 48 -> 24
+    (2, 24, 24, 128, 128, 3, 0, 1, 0, 1), (1, 8, 24, 256, 128, 1, 0, 1, 0, 1), (1, 16, 40, 64, 128, 3, 0, 0, 0, 0),
+    (1, 24, 24, 128, 3, 3, 0, 0, 1, 1), (1, 48, 24, 64, 128, 3, 1, 0, 0, 0),
 ])
 def test_conv_fused_vs_fp32_reference(B, H, W, Cin, Cout, k, ups, res, nchw, gn):
     """lgen_conv_fused (GroupNorm-apply + swish + split on the tile load, halo tile in LDS, bias / residual / next-norm
@@ -315,7 +318,7 @@ def test_conv_fused_vs_fp32_reference(B, H, W, Cin, Cout, k, ups, res, nchw, gn)
         L.check(lib.lgen_gn_stats(L.ptr(xd), L.ptr(ws), L.ptr(st), B, Hs * Ws, Cin, 1e-6, nchunk, L.stream()), "stats")
         coef = torch.empty(B, Cin, 2, device=dev)
         g_d, b_d = gamma.to(dev), beta.to(dev)
-        L.check(lib.lgen_gn_finalize(0, L.ptr(st), L.ptr(g_d), L.ptr(b_d), L.ptr(coef), B, Cin, 0, 0, Hs * Ws, 1e-6, L.stream()), "fin")
+        L.check(lib.lgen_gn_finalize(0, L.ptr(st), L.ptr(g_d), L.ptr(b_d), L.ptr(coef), B, Cin, 0, 0, Hs * Ws, 0, 1e-6, L.stream()), "fin")
         xin = F.group_norm(xin, 32, gamma.double(), beta.double(), eps=1e-6)
         xin = xin * torch.sigmoid(xin)
     if ups:
@@ -325,25 +328,32 @@ def test_conv_fused_vs_fp32_reference(B, H, W, Cin, Cout, k, ups, res, nchw, gn)
         ref = ref + r.permute(0, 3, 1, 2)
     r_d = r.to(dev).contiguous() if res else None
     out = torch.full((B * H * W * Cout,), float("nan"), device=dev)
-    ntiles = (H // 8) * (W // 16)
+    tiles_x = (W + 15) // 16
+    ntiles = (H // 8) * tiles_x
     part = torch.full((B, ntiles, cw.fnpad // 4, 2), float("nan"), device=dev)
     L.check(lib.lgen_conv_fused(L.ptr(xd), L.ptr(coef), 1 if gn else 0, L.ptr(cw.frag), L.ptr(cw.bias), L.ptr(r_d), L.ptr(out),
                                 L.ptr(part), B, H, W, Cin, Cout, cw.fnpad, k, ups, nchw, L.stream()), "conv_fused")
     got = out.cpu().view(B, Cout, H, W) if nchw else out.cpu().view(B, H, W, Cout).permute(0, 3, 1, 2)
+    assert torch.isfinite(got).all()   # every pixel of the map was written (masked tile columns included)
     err = (got - ref).abs().max().item()
     assert err < 6e-5 * max(1.0, ref.abs().max().item()), err
-    # statistics of what was stored, per (image, 4-channel quad), summed over tiles
+    # statistics of what was stored, per (image, tile, 4-channel quad): (sum, M2 about the tile's own mean)
     nq = (Cout + 3) // 4
-    gq = torch.zeros(B, nq * 4, H * W)
-    gq[:, :Cout] = got.reshape(B, Cout, H * W)
-    gq = gq.view(B, nq, 4 * H * W).double()
-    ps = part.cpu().double().sum(1)[:, :nq]
-    np.testing.assert_allclose(ps[..., 0].numpy(), gq.sum(-1).numpy(), rtol=1e-5, atol=1e-3)
-    np.testing.assert_allclose(ps[..., 1].numpy(), (gq ** 2).sum(-1).numpy(), rtol=1e-5, atol=1e-3)
+    gq = torch.zeros(B, nq * 4, H, W, dtype=torch.float64)
+    gq[:, :Cout] = got.double()
+    pc = part.cpu().double()
+    for ty in range(H // 8):
+        for tx in range(tiles_x):
+            blk = gq[:, :, ty * 8:ty * 8 + 8, tx * 16:min(W, tx * 16 + 16)]
+            blk = blk.reshape(B, nq, 4, -1).reshape(B, nq, -1)
+            S = blk.sum(-1)
+            M2 = ((blk - blk.mean(-1, keepdim=True)) ** 2).sum(-1)
+            np.testing.assert_allclose(pc[:, ty * tiles_x + tx, :nq, 0].numpy(), S.numpy(), rtol=1e-5, atol=1e-3)
+            np.testing.assert_allclose(pc[:, ty * tiles_x + tx, :nq, 1].numpy(), M2.numpy(), rtol=1e-4, atol=1e-3)
     if Cout % 128 == 0:
         g2, b2 = (1 + 0.1 * _rand((Cout,), 10)).to(dev), (0.1 * _rand((Cout,), 11)).to(dev)
         c2 = torch.empty(B, Cout, 2, device=dev)
-        L.check(lib.lgen_gn_finalize(L.ptr(part), 0, L.ptr(g2), L.ptr(b2), L.ptr(c2), B, Cout, ntiles, cw.fnpad // 4, H * W, 1e-6,
+        L.check(lib.lgen_gn_finalize(L.ptr(part), 0, L.ptr(g2), L.ptr(b2), L.ptr(c2), B, Cout, ntiles, cw.fnpad // 4, H * W, W, 1e-6,
                                      L.stream()), "fin2")
         gg = got.reshape(B, 32, -1).double()
         mean, var = gg.mean(-1), gg.var(-1, unbiased=False)
@@ -353,6 +363,40 @@ def test_conv_fused_vs_fp32_reference(B, H, W, Cin, Cout, k, ups, res, nchw, gn)
         sh = b2.cpu().double() - sc * mean.repeat_interleave(gs, 1)
         np.testing.assert_allclose(c2[..., 0].cpu().numpy(), sc.float().numpy(), rtol=2e-5)
         np.testing.assert_allclose(c2[..., 1].cpu().numpy(), sh.float().numpy(), rtol=2e-5, atol=2e-5)
+
+
+def test_fused_groupnorm_statistics_survive_a_large_offset():
+    """ADVICE (round 2): sum / sum-of-squares partials lose the variance to cancellation when |mean| >> std.  A 1x1 convolution with
+    tiny weights and a large bias stores values 60 +- 0.02; the (sum, M2) partials + Chan combine must still give the fp64
+    GroupNorm coefficients (the old E[x^2] - mean^2 form is off by orders of magnitude here)."""
+    from llamagen_amd.vq_engine import _ConvW
+    L, dev = _L(), _dev()
+    lib = L.lib()
+    B, H, W, C = 2, 16, 24, 128
+
+    class Cv:
+        pass
+    cv = Cv()
+    cv.weight = (2e-3 * _rand((C, C, 1, 1), 14)).to(dev)
+    cv.bias = (60.0 + 0.01 * _rand((C,), 15)).to(dev)
+    cw = _ConvW(cv)
+    x = _rand((B, H, W, C), 16)
+    xd = x.to(dev).contiguous()
+    out = torch.empty(B * H * W * C, device=dev)
+    ntiles = (H // 8) * ((W + 15) // 16)
+    part = torch.empty(B, ntiles, cw.fnpad // 4, 2, device=dev)
+    L.check(lib.lgen_conv_fused(L.ptr(xd), 0, 0, L.ptr(cw.frag), L.ptr(cw.bias), 0, L.ptr(out), L.ptr(part), B, H, W, C, C, cw.fnpad,
+                                1, 0, 0, L.stream()), "conv_fused")
+    g2, b2 = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    c2 = torch.empty(B, C, 2, device=dev)
+    L.check(lib.lgen_gn_finalize(L.ptr(part), 0, L.ptr(g2), L.ptr(b2), L.ptr(c2), B, C, ntiles, cw.fnpad // 4, H * W, W, 1e-6,
+                                 L.stream()), "fin")
+    gg = out.cpu().view(B, H * W, 32, C // 32).permute(0, 2, 1, 3).reshape(B, 32, -1).double()
+    mean, var = gg.mean(-1), gg.var(-1, unbiased=False)
+    assert (mean.abs() / var.sqrt()).min() > 500          # the regime the advice is about
+    rstd = (1 / torch.sqrt(var + 1e-6)).repeat_interleave(C // 32, 1)
+    np.testing.assert_allclose(c2[..., 0].cpu().numpy(), rstd.float().numpy(), rtol=2e-3)
+    np.testing.assert_allclose(c2[..., 1].cpu().numpy(), (-rstd * mean.repeat_interleave(C // 32, 1)).float().numpy(), rtol=2e-3)
 
 
 def test_decode_code_fused_matches_unfused(monkeypatch):

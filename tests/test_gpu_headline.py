@@ -251,6 +251,9 @@ def test_fused_norm_gemm_passes_bit_identical(M):
     dx = (xn - xn_ref).abs()
     assert (dx > 0).float().mean().item() < 1e-3 and (dx <= xn_ref.abs() * 2.0 ** -7 + 1e-30).all(), ((dx > 0).sum().item(), dx.max().item())
     ref_rows = O.linear(xn, wh.float(), dt)
+    a1, a3 = O.linear(xn, w1.float(), dt), O.linear(xn, w3.float(), dt)
+    ref_gp = O._rnd(O._rnd(torch.nn.functional.silu(a1), dt) * a3, dt)
+    ref_v = O.linear(xn, wq.float(), dt)[:, 2 * d:].reshape(M, H, hd)
     first = None
     for tile in [(2, 4), (1, 4), (2, 2), (4, 2)]:  # qkv (4, 2) has no multi-pass form (register budget): falls back to one pass
         if tile[0] > mts:
@@ -377,3 +380,35 @@ def test_config3_gptxxl_shapes_bf16_vs_oracle():
     recs, m = _teacher_forced(case, B, 4.0, early=3, late=[575], cond=cond)
     assert m._engine.fuse_norm
     _check("config3_gptxxl_shapes", recs)
+
+
+@pytest.mark.parametrize("name,registry,kw,B,cfg_scale,late", [
+    ("config3_gptxxl_full_depth", "GPT-XXL", dict(vocab_size=16384, block_size=576, num_classes=1000, cls_token_num=1, model_type="c2i"),
+     2, 4.0, [575]),
+    ("config4_gpt3b_full_depth", "GPT-3B", dict(vocab_size=16384, block_size=576, num_classes=1000, cls_token_num=1, model_type="c2i"),
+     2, 4.0, [420]),
+    ("config5_gptxl_t2i_full_depth", "GPT-XL", dict(vocab_size=16384, block_size=1024, cls_token_num=120, caption_dim=2048, model_type="t2i"),
+     2, 7.5, [1142]),
+])
+def test_configs_3_4_5_full_depth_vs_oracle(name, registry, kw, B, cfg_scale, late):
+    """BASELINE configs 3 / 4 / 5 at FULL depth (GPT-XXL 48 layers, GPT-3B 24, GPT-XL t2i 36) with two images per batch: prefill,
+    two early positions and one late position on injected cache contents, same bar as the config-2 tests.  The oracle needs
+    minutes per model on the host cores, so this runs only on request (LGEN_SLOW=1; tools/run_slow_parity.sh keeps the distances in
+    profiles/r03_full_depth_parity.jsonl)."""
+    if os.environ.get("LGEN_SLOW") != "1":
+        pytest.skip("full-depth parity of the big configs: set LGEN_SLOW=1 (minutes of CPU oracle time per model)")
+    case = dict(registry=registry, kwargs=kw, wseed=31, lin_std=0.02)
+    g = torch.Generator().manual_seed(9)
+    if kw["model_type"] == "c2i":
+        recs, m = _teacher_forced(case, B, cfg_scale, early=2, late=late, cond=torch.randint(0, 1000, (B,), generator=g))
+    else:
+        T = kw["cls_token_num"]
+        emb = torch.randn(B, T, kw["caption_dim"], generator=g)
+        lens = torch.randint(5, T + 1, (B,), generator=g)
+        mask = torch.zeros(B, T, dtype=torch.int64)
+        for b in range(B):
+            mask[b, T - int(lens[b]):] = 1
+        emb = (emb * mask[:, :, None]).to(torch.bfloat16).float()
+        recs, m = _teacher_forced(case, B, cfg_scale, early=2, late=late, cond=emb, emb_masks=mask, T=T)
+    assert len(m._engine.layers) == {"GPT-XXL": 48, "GPT-3B": 24, "GPT-XL": 36}[registry]
+    _check(name, recs)

@@ -70,3 +70,48 @@ def test_staggered_arrivals_and_generate_agreement():
     for rid, label, nz in zip(ids, labels, noises):
         ref = generate(m2, torch.tensor([label], device="cuda:0"), N, _noise_seq=nz.view(N, 1, V), **skw)
         assert torch.equal(out[rid].cpu(), ref[0].cpu()), rid
+
+
+KW_T2I = dict(n_layer=2, n_head=4, dim=256, vocab_size=1024, block_size=16, cls_token_num=120, caption_dim=64, model_type="t2i")
+
+
+@pytest.mark.parametrize("cfg_scale,slots", [(7.5, 2), (1.0, 3)])
+def test_text_conditional_requests_with_staggered_arrivals(cfg_scale, slots):
+    """Round 3: t2i requests (120-token caption prefix prefilled per request on a private engine, then joined to the slot batch at
+    position T).  Requests arrive while others are mid-sequence; every one must equal the oracle's batch-of-one generate() with its
+    caption, emb_mask and noise, token for token (fp32 storage)."""
+    from llamagen_amd.serve import ContinuousBatcher
+    m = Transformer(ModelArgs(**KW_T2I))
+    sd = synth_for_module(m, seed=7, lin_std=0.05)
+    m.load_state_dict(sd, strict=False)
+    m = m.to(device=torch.device("cuda:0"), dtype=torch.float32).eval()
+    N, V, T, C, nreq = 16, KW_T2I["vocab_size"], 120, 64, 5
+    g = torch.Generator().manual_seed(21)
+    caps, masks = [], []
+    for _ in range(nreq):
+        n = int(torch.randint(1, T + 1, (1,), generator=g))
+        mk = torch.zeros(T, dtype=torch.int64)
+        mk[T - n:] = 1                                     # left-padded: valid tokens at the end (sample_t2i.py:95-107)
+        caps.append(torch.randn(T, C, generator=g) * mk[:, None])
+        masks.append(mk)
+    noises = [torch.empty(N, V).exponential_(1, generator=g) for _ in range(nreq)]
+    skw = dict(cfg_scale=cfg_scale, cfg_interval=-1, temperature=1.0, top_k=100, top_p=1.0, sample_logits=True)
+    cb = ContinuousBatcher(m, slots, N, **skw)
+    ids = [cb.submit(caps[0], noises[0], masks[0])]
+    out = {}
+    cb._load(0, *cb._queue.popleft())                      # one request alone for 4 steps, then the rest arrive
+    for _ in range(4):
+        cb._step()
+        cb.steps_run += 1
+        cb._account(out)
+    ids += [cb.submit(c, n, k) for c, n, k in zip(caps[1:], noises[1:], masks[1:])]
+    out.update(cb.run())
+    torch.cuda.synchronize()
+    assert sorted(out) == ids
+    model = O.GPTOracle(O.GPTConfig(**KW_T2I), sd, torch.float32)
+    for rid, cap, mk, nz in zip(ids, caps, masks, noises):
+        it = iter(nz)
+        ref = O.generate(model, cap.unsqueeze(0), N, emb_masks=mk.unsqueeze(0), noise_fn=lambda shape: next(it).view(1, -1), **skw)
+        np.testing.assert_array_equal(out[rid].cpu().numpy(), ref[0].numpy(), err_msg=f"request {rid}")
+    with pytest.raises(ValueError):
+        cb.submit(torch.zeros(T - 1, C))

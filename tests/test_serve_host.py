@@ -11,7 +11,7 @@ from llamagen_amd.serve import ContinuousBatcher
 class _Batcher(ContinuousBatcher):
     def __init__(self, slots, N, cfg=True):  # the real constructor builds a DecodeEngine on the GPU
         self.B, self.N, self.use_cfg = slots, N, cfg
-        self.num_classes, self.V = 1000, 32
+        self.num_classes, self.V, self.t2i, self.T = 1000, 32, False, 1
         self.B2 = 2 * slots if cfg else slots
         R = 16
         self.dev = torch.device("cpu")

@@ -1,0 +1,56 @@
+"""Throughput of token-level continuous batching (llamagen_amd/serve.py) against the batch-level pipeline on the same workload
+(development aid, round 3): GPT-L 384 px class-conditional requests, cfg 4.0, top-k 2000, decode only (no VQ).
+    python tools/serve_bench.py [slots ...]        (default 32 64)
+Prints requests/s and tokens/s for ContinuousBatcher(slots) draining 3 x slots requests that are all queued at t = 0, and for
+SamplingPipeline on the same number of images (one chain of `slots` images at a time)."""
+import os, sys, time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+from llamagen_amd.pipeline import SamplingPipeline
+from llamagen_amd.serve import ContinuousBatcher
+
+dev = torch.device("cuda:0")
+N = 576
+skw = dict(cfg_scale=4.0, cfg_interval=-1, temperature=1.0, top_k=2000, top_p=1.0, sample_logits=True)
+
+
+def main():
+    torch.set_grad_enabled(False)
+    gpt, _ = bench.build_models(dev, 0)
+    for slots in [int(a) for a in sys.argv[1:]] or [32, 64]:
+        nreq = 3 * slots
+        labels = torch.randint(0, 1000, (nreq,)).tolist()
+        cb = ContinuousBatcher(gpt, slots, N, **skw)
+        for l in labels[:slots]:                      # warm-up round: kernels, graph capture
+            cb.submit(l)
+        cb.run()
+        torch.cuda.synchronize()
+        for l in labels:
+            cb.submit(l)
+        t = time.perf_counter()
+        out = cb.run()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t
+        assert len(out) == nreq
+        print(f"ContinuousBatcher slots={slots}: {nreq} requests in {dt:.2f} s = {nreq / dt:.1f} requests/s, {nreq * N / dt / 1e3:.1f} k tokens/s "
+              f"({cb.steps_run} steps)", flush=True)
+        del cb
+        gpt._engine = None
+        torch.cuda.empty_cache()
+        pipe = SamplingPipeline(gpt, None, lanes=1)
+        pipe.prepare(slots, N, **skw)
+        conds = [torch.randint(0, 1000, (slots,), device=dev) for _ in range(3)]
+        torch.cuda.synchronize(); t = time.perf_counter()
+        pipe.run(conds, N, **skw)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t
+        print(f"SamplingPipeline  batch={slots}: {nreq} images in {dt:.2f} s = {nreq / dt:.1f} images/s, {nreq * N / dt / 1e3:.1f} k tokens/s", flush=True)
+        del pipe
+        gpt._engine = None
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()

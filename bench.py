@@ -692,7 +692,7 @@ def main():
 
 
 DEFAULT_BPC = 4          # c2i: consecutive batches per decode chain (256 rows at config 2)
-PMC_JSON = "r02_pmc.json"
+PMC_JSON = "r03_pmc.json"
 
 
 def PMC_POSITIONS(N, T=1):

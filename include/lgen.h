@@ -245,7 +245,7 @@ int lgen_prefetch_hint(const void* next_weights, long long bytes);
 int lgen_gemm_schedule_hint(int passes, int double_buffer);
 
 /* ---- tuning knobs (process-wide kernel variant selection; defaults are the measured-best ones) ---- */
-int lgen_set_attn_variant(int v);  /* (K/V loads per buffer, waves per (b,h)): 2 (default) = (2,2); 1 = (2,4); 0 = (4,4); 3 = (4,2); 4 = (2,1); 5 = (4,1) */
+int lgen_set_attn_variant(int v);  /* (K/V loads per buffer, waves per (b,h)): 2 (default) = (2,2); 1 = (2,4); 0 = (4,4); 3 = (4,2); 4 = (2,1); 5 = (4,1); 6 / 7 = (2,2) with 2 / 4 heads of a row per workgroup (n_head must be a multiple) */
 int lgen_set_vq_nt(int v);         /* VQ decoder: non-temporal fp32 activation stores / GroupNorm-pass loads (0 = off) */
 int lgen_set_prefill_mfma(int v);       /* lgen_attn_prefill, bf16: 1 (default) MFMA flash kernel; 0 the VALU kernels (always used for fp32) */
 int lgen_set_conv_fused_variant(int v); /* lgen_conv_fused weight tiles: 1 (default) global -> LDS DMA; 0 through staging registers */

@@ -255,16 +255,21 @@ struct AttnArgs {
     long long pf_bytes;
 };
 
-template <typename D, int LPK, int ATT_CH, int ATT_NW>
-__global__ __launch_bounds__(64 * ATT_NW, (ATT_CH <= 2 ? 4 : 2)) void attn_decode_kernel(AttnArgs a) {
+// HPW (round 3): (batch row, head) pairs per workgroup.  At 256 chain rows the grid is 4096 (b, h) pairs; dispatching that many
+// 128-thread workgroups is 9 us of a 52 us average launch (kv_len 1: 9.0 us at 256 rows against 4.6 us at 64), so wide chains put
+// 2 or 4 heads of one row into a workgroup (same kv_len: the waves stay balanced across the one barrier).
+template <typename D, int LPK, int ATT_CH, int ATT_NW, int HPW>
+__global__ __launch_bounds__(64 * ATT_NW * HPW, (ATT_CH <= 2 ? 4 : 2)) void attn_decode_kernel(AttnArgs a) {
     constexpr int KPL = 64 / LPK;            // keys per wave-load
     constexpr int EPL = D::EPL;
     constexpr int GK = ATT_CH * KPL;         // keys per group
-    __shared__ float s_m[ATT_NW], s_l[ATT_NW];
-    __shared__ float s_acc[ATT_NW][LPK * EPL];
+    __shared__ float s_m[HPW][ATT_NW], s_l[HPW][ATT_NW];
+    __shared__ float s_acc[HPW][ATT_NW][LPK * EPL];
     const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+    const int wvall = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hg = wvall / ATT_NW, wv = wvall - hg * ATT_NW;   // head of this wave inside the workgroup, wave inside the head
+    const int bh = blockIdx.x * HPW + hg;
+    const int b = bh / a.H, h = bh - b * a.H;
     const int part = lane % LPK, kin = lane / LPK;
     const size_t rowbase = ((size_t)b * a.H + h) * a.S8;
     const int lpr = a.hdp / EPL;             // 16-byte pieces per key row (== LPK)
@@ -273,7 +278,7 @@ __global__ __launch_bounds__(64 * ATT_NW, (ATT_CH <= 2 ? 4 : 2)) void attn_decod
     const uint4* vp = (const uint4*)a.vc + rowbase * rpr + part;
     const int smax = a.S8 - 1;
 
-    const unsigned pf_token = prefetch_lines(a.pf, a.pf_bytes, blockIdx.x * ATT_NW + wv, gridDim.x * ATT_NW, lane);
+    const unsigned pf_token = prefetch_lines(a.pf, a.pf_bytes, blockIdx.x * ATT_NW * HPW + wvall, gridDim.x * ATT_NW * HPW, lane);
     uint4 k0[ATT_CH], v0[ATT_CH], k1[ATT_CH], v1[ATT_CH];
 #define ATT_LOAD(KB, VB, g)                                                 \
     {                                                                       \
@@ -352,26 +357,27 @@ __global__ __launch_bounds__(64 * ATT_NW, (ATT_CH <= 2 ? 4 : 2)) void attn_decod
     }
     if (lane < LPK) {
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) s_acc[wv][lane * EPL + e] = acc[e];
+        for (int e = 0; e < EPL; ++e) s_acc[hg][wv][lane * EPL + e] = acc[e];
     }
-    if (lane == 0) { s_m[wv] = m_run; s_l[wv] = l_run; }
+    if (lane == 0) { s_m[hg][wv] = m_run; s_l[hg][wv] = l_run; }
     __syncthreads();
-    for (int t = threadIdx.x; t < a.hd; t += 64 * ATT_NW) {
-        float M = s_m[0];
+    for (int t = wv * 64 + lane; t < a.hd; t += 64 * ATT_NW) {
+        float M = s_m[hg][0];
 #pragma unroll
-        for (int i = 1; i < ATT_NW; ++i) M = fmaxf(M, s_m[i]);
+        for (int i = 1; i < ATT_NW; ++i) M = fmaxf(M, s_m[hg][i]);
         float L = 0.f, o = 0.f;
 #pragma unroll
         for (int i = 0; i < ATT_NW; ++i) {
-            const float f = D::fexp(s_m[i] - M);
-            L += s_l[i] * f;
-            o += s_acc[i][t] * f;
+            const float f = D::fexp(s_m[hg][i] - M);
+            L += s_l[hg][i] * f;
+            o += s_acc[hg][i][t] * f;
         }
         o = o / L;
         D::st(a.out, D::xp_off(h * a.hd + t, b >> 4, b & 15, a.MTs), o);
     }
 }
 
+// variants 6 / 7 (round 3): (2, 2) with 2 / 4 heads of a row per workgroup (wide chains: fewer workgroups to dispatch).
 // variant (ATT_CH K/V loads per buffer, waves per (b, h) workgroup): 2 = default (2, 2): 128-thread workgroups,
 // every workgroup of a B2 x H = 1024 grid resident at once, lowest fixed cost (4.4 us at kv_len 1 vs 6.1 us with
 // 4 waves) and the same 6.4 TB/s incremental rate at long kv_len; 1 = (2, 4); 0 = (4, 4); 3 = (4, 2); 4 = (2, 1); 5 = (4, 1)
@@ -393,16 +399,20 @@ static int attn_decode_impl(const void* q, const void* k_cache, const void* v_ca
     if (dtype != LGEN_BF16 && dtype != LGEN_F32 && dtype != LGEN_F16) return LGEN_ERR_BAD_ARG;
     if (hdp % epl || hd > hdp || B2 > MTs * 16 || S8 < 1 || a.kvs < hdp || a.kvs % epl) return LGEN_ERR_BAD_ARG;
     const int lpk = hdp / epl;
-    const int nw = g_attn_variant >= 4 ? 1 : (g_attn_variant >= 2 ? 2 : 4);
-    dim3 grid(B2 * n_head), block(64 * nw);
+    const int hpw = g_attn_variant == 6 ? 2 : (g_attn_variant == 7 ? 4 : 1);
+    if (n_head % hpw) return LGEN_ERR_BAD_ARG;
+    const int nw = g_attn_variant >= 6 ? 2 : (g_attn_variant >= 4 ? 1 : (g_attn_variant >= 2 ? 2 : 4));
+    dim3 grid(B2 * n_head / hpw), block(64 * nw * hpw);
 #define LGEN_ATT(DT, L)                                                                              \
     do {                                                                                             \
-        if (g_attn_variant == 1) hipLaunchKernelGGL((attn_decode_kernel<DT, L, 2, 4>), grid, block, 0, st, a);      \
-        else if (g_attn_variant == 2) hipLaunchKernelGGL((attn_decode_kernel<DT, L, 2, 2>), grid, block, 0, st, a); \
-        else if (g_attn_variant == 3) hipLaunchKernelGGL((attn_decode_kernel<DT, L, 4, 2>), grid, block, 0, st, a); \
-        else if (g_attn_variant == 4) hipLaunchKernelGGL((attn_decode_kernel<DT, L, 2, 1>), grid, block, 0, st, a); \
-        else if (g_attn_variant == 5) hipLaunchKernelGGL((attn_decode_kernel<DT, L, 4, 1>), grid, block, 0, st, a); \
-        else hipLaunchKernelGGL((attn_decode_kernel<DT, L, 4, 4>), grid, block, 0, st, a);                          \
+        if (g_attn_variant == 1) hipLaunchKernelGGL((attn_decode_kernel<DT, L, 2, 4, 1>), grid, block, 0, st, a);      \
+        else if (g_attn_variant == 2) hipLaunchKernelGGL((attn_decode_kernel<DT, L, 2, 2, 1>), grid, block, 0, st, a); \
+        else if (g_attn_variant == 3) hipLaunchKernelGGL((attn_decode_kernel<DT, L, 4, 2, 1>), grid, block, 0, st, a); \
+        else if (g_attn_variant == 4) hipLaunchKernelGGL((attn_decode_kernel<DT, L, 2, 1, 1>), grid, block, 0, st, a); \
+        else if (g_attn_variant == 5) hipLaunchKernelGGL((attn_decode_kernel<DT, L, 4, 1, 1>), grid, block, 0, st, a); \
+        else if (g_attn_variant == 6) hipLaunchKernelGGL((attn_decode_kernel<DT, L, 2, 2, 2>), grid, block, 0, st, a); \
+        else if (g_attn_variant == 7) hipLaunchKernelGGL((attn_decode_kernel<DT, L, 2, 2, 4>), grid, block, 0, st, a); \
+        else hipLaunchKernelGGL((attn_decode_kernel<DT, L, 4, 4, 1>), grid, block, 0, st, a);                          \
     } while (0)
     if (dtype == LGEN_BF16 && lpk == 8) LGEN_ATT(BF16, 8);
     else if (dtype == LGEN_BF16 && lpk == 16) LGEN_ATT(BF16, 16);

@@ -259,7 +259,9 @@ def test_qkv_rope_append_and_attention(dt, B2, H, hd, grid, pos, interleave):
     vc_d[..., :hd] = vref.to(dt).to(dev)
     q_d[:B2, :, :hd] = xq[:, 0].to(dt).to(dev)
     kcd = _kc(dt)
-    for use_mask, variant in ((False, 0), (True, 0), (False, 1), (True, 1), (False, 2), (True, 3), (True, 4), (False, 5)):
+    variants = [(False, 0), (True, 0), (False, 1), (True, 1), (False, 2), (True, 3), (True, 4), (False, 5)]
+    variants += [(um, v) for v, hpw in ((6, 2), (7, 4)) if H % hpw == 0 for um in (False, True)]  # round 3: 2 / 4 heads per workgroup
+    for use_mask, variant in variants:
         L.lib().lgen_set_attn_variant(variant)
         mask = torch.tril(torch.ones(S8, S8, dtype=torch.bool)).unsqueeze(0).repeat(B2, 1, 1)
         if use_mask:

@@ -249,7 +249,8 @@ def test_fused_norm_gemm_passes_bit_identical(M):
     xn_ref = O.rms_norm(x.float(), nw, 1e-5, dt)
     xn = xrows[:M].float().cpu()
     dx = (xn - xn_ref).abs()
-    assert (dx > 0).float().mean().item() < 1e-3 and (dx <= xn_ref.abs() * 2.0 ** -7 + 1e-30).all(), ((dx > 0).sum().item(), dx.max().item())
+    assert (dx > 0).float().mean().item() < 1e-3 and (dx <= torch.maximum(xn.abs(), xn_ref.abs()) * 2.0 ** -7 * 1.01).all(), \
+        ((dx > 0).sum().item(), dx.max().item())   # at most one bf16 ulp (of the larger value: a flip may cross a binade)
     ref_rows = O.linear(xn, wh.float(), dt)
     a1, a3 = O.linear(xn, w1.float(), dt), O.linear(xn, w3.float(), dt)
     ref_gp = O._rnd(O._rnd(torch.nn.functional.silu(a1), dt) * a3, dt)

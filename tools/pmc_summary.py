@@ -1,11 +1,11 @@
-"""rocprofv3 counter_collection.csv (FETCH_SIZE pass, WRITE_SIZE pass of tools/pmc_target.py) -> profiles/r02_pmc.json and a
-readable profiles/r02_pmc.csv.  FETCH_SIZE is in KB and counts HALF of a wide coalesced read stream on gfx950
+"""rocprofv3 counter_collection.csv (FETCH_SIZE pass, WRITE_SIZE pass of tools/pmc_target.py) -> profiles/r03_pmc.json and a
+readable profiles/r03_pmc.csv.  FETCH_SIZE is in KB and counts HALF of a wide coalesced read stream on gfx950
 (MI355X_MICROARCH.md, HBM section): bytes = KB * 1024 * 2; WRITE_SIZE: bytes = KB * 1024."""
 import csv, glob, json, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 d, H, hd, F, V = 1024, 16, 64, 2816, 16384
-B2 = 2 * int(os.environ.get("LGEN_PMC_B", "64"))  # rows of the decode chain (tools/pmc_target.py)
+B2 = 2 * int(os.environ.get("LGEN_PMC_B", "128"))  # rows of the decode chain (tools/pmc_target.py)
 GEMM = {  # kernel-name fragment -> (bench key, algorithmic weight bytes)
     "EPI_QKV": ("wqkv", 3 * d * d * 2), "5, 4>(GemmArgs)": ("wqkv", 3 * d * d * 2),
 }
@@ -38,7 +38,7 @@ def classify(name, grid):
 
 
 def main(fetch_dir, write_dir):
-    res = {"gemm": {"source": "profiles/r02_pmc.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/pmc_target.py)"}}
+    res = {"gemm": {"source": "profiles/r03_pmc.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/pmc_target.py)"}}
     table = []
     for counter, ddir, scale in (("FETCH_SIZE", fetch_dir, 2048.0), ("WRITE_SIZE", write_dir, 1024.0)):
         acc = {}
@@ -92,8 +92,8 @@ def main(fetch_dir, write_dir):
     res.setdefault("attn_decode_kernel", {})["source"] = res["gemm"]["source"]
     res["rows"] = B2
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
-    json.dump(res, open(os.path.join(ROOT, "profiles", "r02_pmc.json"), "w"), indent=1)
-    with open(os.path.join(ROOT, "profiles", "r02_pmc.csv"), "w") as f:
+    json.dump(res, open(os.path.join(ROOT, "profiles", "r03_pmc.json"), "w"), indent=1)
+    with open(os.path.join(ROOT, "profiles", "r03_pmc.csv"), "w") as f:
         f.write(f"# rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separate pass, WRITE_SIZE) -- python tools/pmc_target.py ; GPT-L bf16, B2 = {B2}\n")
         f.write("# FETCH_SIZE KB x 1024 x 2 (gfx950 correction for wide coalesced reads, MI355X_MICROARCH.md); WRITE_SIZE KB x 1024\n")
         f.write("counter,kernel,launches,bytes_per_launch,algorithmic_bytes,ratio\n")

@@ -399,19 +399,22 @@ static int attn_decode_impl(const void* q, const void* k_cache, const void* v_ca
     if (dtype != LGEN_BF16 && dtype != LGEN_F32 && dtype != LGEN_F16) return LGEN_ERR_BAD_ARG;
     if (hdp % epl || hd > hdp || B2 > MTs * 16 || S8 < 1 || a.kvs < hdp || a.kvs % epl) return LGEN_ERR_BAD_ARG;
     const int lpk = hdp / epl;
-    const int hpw = g_attn_variant == 6 ? 2 : (g_attn_variant == 7 ? 4 : 1);
+    // default variant 2; chains of >= 256 rows put two heads of a row into a workgroup (variant 6: 49.8 vs 50.7 us average launch
+    // at 256 rows, 27.3 vs 27.0 at 128: tools/attn_sweep.py, profiles/r03_attn_sweep.log)
+    const int variant = (g_attn_variant == 2 && B2 >= 256 && n_head % 2 == 0) ? 6 : g_attn_variant;
+    const int hpw = variant == 6 ? 2 : (variant == 7 ? 4 : 1);
     if (n_head % hpw) return LGEN_ERR_BAD_ARG;
-    const int nw = g_attn_variant >= 6 ? 2 : (g_attn_variant >= 4 ? 1 : (g_attn_variant >= 2 ? 2 : 4));
+    const int nw = variant >= 6 ? 2 : (variant >= 4 ? 1 : (variant >= 2 ? 2 : 4));
     dim3 grid(B2 * n_head / hpw), block(64 * nw * hpw);
 #define LGEN_ATT(DT, L)                                                                              \
     do {                                                                                             \
-        if (g_attn_variant == 1) hipLaunchKernelGGL((attn_decode_kernel<DT, L, 2, 4, 1>), grid, block, 0, st, a);      \
-        else if (g_attn_variant == 2) hipLaunchKernelGGL((attn_decode_kernel<DT, L, 2, 2, 1>), grid, block, 0, st, a); \
-        else if (g_attn_variant == 3) hipLaunchKernelGGL((attn_decode_kernel<DT, L, 4, 2, 1>), grid, block, 0, st, a); \
-        else if (g_attn_variant == 4) hipLaunchKernelGGL((attn_decode_kernel<DT, L, 2, 1, 1>), grid, block, 0, st, a); \
-        else if (g_attn_variant == 5) hipLaunchKernelGGL((attn_decode_kernel<DT, L, 4, 1, 1>), grid, block, 0, st, a); \
-        else if (g_attn_variant == 6) hipLaunchKernelGGL((attn_decode_kernel<DT, L, 2, 2, 2>), grid, block, 0, st, a); \
-        else if (g_attn_variant == 7) hipLaunchKernelGGL((attn_decode_kernel<DT, L, 2, 2, 4>), grid, block, 0, st, a); \
+        if (variant == 1) hipLaunchKernelGGL((attn_decode_kernel<DT, L, 2, 4, 1>), grid, block, 0, st, a);      \
+        else if (variant == 2) hipLaunchKernelGGL((attn_decode_kernel<DT, L, 2, 2, 1>), grid, block, 0, st, a); \
+        else if (variant == 3) hipLaunchKernelGGL((attn_decode_kernel<DT, L, 4, 2, 1>), grid, block, 0, st, a); \
+        else if (variant == 4) hipLaunchKernelGGL((attn_decode_kernel<DT, L, 2, 1, 1>), grid, block, 0, st, a); \
+        else if (variant == 5) hipLaunchKernelGGL((attn_decode_kernel<DT, L, 4, 1, 1>), grid, block, 0, st, a); \
+        else if (variant == 6) hipLaunchKernelGGL((attn_decode_kernel<DT, L, 2, 2, 2>), grid, block, 0, st, a); \
+        else if (variant == 7) hipLaunchKernelGGL((attn_decode_kernel<DT, L, 2, 2, 4>), grid, block, 0, st, a); \
         else hipLaunchKernelGGL((attn_decode_kernel<DT, L, 4, 4, 1>), grid, block, 0, st, a);                          \
     } while (0)
     if (dtype == LGEN_BF16 && lpk == 8) LGEN_ATT(BF16, 8);

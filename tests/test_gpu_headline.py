@@ -249,8 +249,10 @@ def test_fused_norm_gemm_passes_bit_identical(M):
     xn_ref = O.rms_norm(x.float(), nw, 1e-5, dt)
     xn = xrows[:M].float().cpu()
     dx = (xn - xn_ref).abs()
-    assert (dx > 0).float().mean().item() < 1e-3 and (dx <= torch.maximum(xn.abs(), xn_ref.abs()) * 2.0 ** -7 * 1.01).all(), \
-        ((dx > 0).sum().item(), dx.max().item())   # at most one bf16 ulp (of the larger value: a flip may cross a binade)
+    # a flipped element moved by one bf16 ulp of the INTERMEDIATE rnd(x * scale); times a norm weight < 1 that can be two ulps of
+    # the (smaller-binade) result
+    assert (dx > 0).float().mean().item() < 1e-3 and (dx <= torch.maximum(xn.abs(), xn_ref.abs()) * 2.0 ** -6 * 1.01).all(), \
+        ((dx > 0).sum().item(), dx.max().item())
     ref_rows = O.linear(xn, wh.float(), dt)
     a1, a3 = O.linear(xn, w1.float(), dt), O.linear(xn, w3.float(), dt)
     ref_gp = O._rnd(O._rnd(torch.nn.functional.silu(a1), dt) * a3, dt)

@@ -300,15 +300,23 @@ def cpu_baseline(steps=16, budget_s=30.0, with_c1=True):
     rows), top-k 2000, bf16 -- on the host cores, as a BOUNDED 32-step slice: `steps` decode steps at the start of the
     sequence and `steps` at its end (kv_len ~ 576), plus the VQ decode of 2 images; images/s = 32 / (mean step time x
     576 + 32 x VQ time per image).  Linear extrapolation, labelled as such.  The thread count is calibrated first, MIN-OF-3 per
-    candidate (torch's intra-op pool thrashes on a big host with one thread per logical core; os.cpu_count() itself is a
-    candidate), and reported next to the core count; `impl` names what ran.  `c1` = BASELINE configs[0] timed in full."""
+    candidate, climbing 8, 16, 32, 64, 128, os.cpu_count() until a candidate's first step is > 2.5x slower than the best so far
+    (torch's intra-op pool thrashes on a big host: one thread per logical core costs minutes per step on the 256-core GPU box),
+    and reported next to the core count; `impl` names what ran.  `c1` = BASELINE configs[0] timed in full."""
     ncpu = os.cpu_count() or 1
     kind, step, vq_decode = _cpu_decode_fns()
     N = LAT * LAT
     best_thr, best_t, sweep = 1, 1e30, {}
     for thr in sorted({t for t in (8, 16, 32, 64, 128, ncpu) if t <= ncpu}) or [ncpu]:
         torch.set_num_threads(thr)
+        t0 = time.time()
         step(N // 2)  # warm-up at this thread count
+        warm = time.time() - t0
+        if warm > 2.5 * best_t:
+            # past the knee: torch's intra-op pool thrashes with more threads than the GEMMs can use (measured on the 256-logical-
+            # core GPU box: 157 ms per step at 16 threads, 593 ms at 64, 193 s at 256).  Record the one sample and stop climbing.
+            sweep[thr] = round(warm * 1e3, 1)
+            break
         t = 1e30
         for _ in range(3):
             t0 = time.time()
@@ -436,7 +444,7 @@ def standin_main(args, rank, local, world, rccl_ranks):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json configs[1..4]; 2 = the headline")
     ap.add_argument("--lanes", type=int, default=0, help="decode chains in flight per GPU (llamagen_amd/pipeline.py); "

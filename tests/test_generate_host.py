@@ -12,6 +12,10 @@ from llamagen_amd.generate import generate
 class _Engine:
     def __init__(self):
         self.call = None
+        self.events = []
+
+    def draw_noise(self, N, B, b0, n):
+        self.events.append(("noise", N, B, b0, n))
 
     def generate_iter(self, model, rows, B, N, masks, sp):
         self.call = dict(rows=rows, B=B, N=N, masks=masks, sp=sp)
@@ -71,3 +75,30 @@ def test_argument_errors_follow_the_reference():
         generate(m, torch.zeros(2, 3, 4), 4, emb_masks=torch.ones(2, 5))
     with pytest.raises(TypeError):
         generate(_model("c2i"), torch.tensor([1]), 4, topk=3)
+
+
+def test_chain_of_batches_draws_labels_and_noise_in_consecutive_generate_order():
+    """pipeline hook `_more_conds` (several batches on one decode chain): batch j's labels are evaluated, then batch j's noise
+    is drawn, THEN batch j + 1's labels -- the order consecutive reference generate() calls consume the default generator
+    (sample_c2i_ddp.py:128-140) -- and the chain's rows are [all conditional rows, then all their null twins]."""
+    m = _model("c2i")
+    ev = m._engine.events
+
+    def batch(i):
+        def f():
+            ev.append(("labels", i))
+            return torch.tensor([10 * i + 1, 10 * i + 2])
+        return f
+    first = batch(0)()
+    generate(m, first, 6, cfg_scale=4.0, _more_conds=[batch(1), batch(2)])
+    assert ev == [("labels", 0), ("noise", 6, 6, 0, 2), ("labels", 1), ("noise", 6, 6, 2, 2), ("labels", 2), ("noise", 6, 6, 4, 2)]
+    c = m._engine.call
+    assert c["B"] == 6 and c["rows"].tolist() == [1, 2, 11, 12, 21, 22] + [1000] * 6 and m.caches == (12, 7, torch.bfloat16)
+    assert c["sp"]["_noise_prefilled"] is True
+    ev.clear()
+    generate(m, torch.tensor([1, 2]), 6, cfg_scale=1.0, sample_logits=False, _more_conds=[torch.tensor([3, 4])])   # greedy: no draws
+    assert ev == [] and m._engine.call["rows"].tolist() == [1, 2, 3, 4] and "_noise_prefilled" not in m._engine.call["sp"]
+    with pytest.raises(ValueError):
+        generate(m, torch.tensor([1, 2]), 6, _more_conds=[torch.tensor([3, 4, 5])])
+    with pytest.raises(NotImplementedError):
+        generate(_model("t2i", 3), torch.zeros(2, 3, 4), 4, _more_conds=[torch.zeros(2, 3, 4)])

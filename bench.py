@@ -505,9 +505,8 @@ def main():
         lens = torch.randint(5, T + 1, (B,), generator=g)
         emb_masks = (torch.arange(T).unsqueeze(0) >= (T - lens).unsqueeze(1)).to(torch.int64).to(dev)
         skw["emb_masks"] = emb_masks
-    bpc = args.batches_per_chain if args.batches_per_chain > 0 else (DEFAULT_BPC if args.config == 2 else 1)
-    if t2i:
-        bpc = 1
+    # batches per decode chain: 256 rows for the 32-image configs (2, 3), 256 for GPT-3B's 64-image batches, 128 for the 16-caption t2i batch
+    bpc = args.batches_per_chain if args.batches_per_chain > 0 else {2: DEFAULT_BPC, 3: 4, 4: 2, 5: 4}[args.config]
     chains = (args.steps + bpc - 1) // bpc
     if args.lanes <= 0:
         # k chains in flight take ~T_k (measured, relative to one chain alone: 1, 1.44, 2.02 at 64 rows; 1, 1.5, 2.1 at 128);
@@ -516,6 +515,13 @@ def main():
         Tk = {0: 0.0, 1: 1.0, 2: 1.44, 3: 2.02} if bpc == 1 else ({0: 0.0, 1: 1.0, 2: 1.5, 3: 2.1} if bpc < 4 else
                                                                    {0: 0.0, 1: 1.0, 2: 1.71, 3: 2.49})
         args.lanes = min((1, 2, 3), key=lambda l: (chains // l) * Tk[l] + Tk[chains % l])
+        # KV slabs + noise of the chains in flight must fit the 288 GB of HBM3E with room for weights and decoder activations
+        cfg_m = gpt.config
+        hdp = 64 if cfg_m.dim // cfg_m.n_head <= 64 else 128
+        per_chain = (cfg_m.n_layer * 2 * B * bpc * cfg_m.n_head * (T + N + 8) * hdp * 2 * 2      # K and V slabs, CFG rows
+                     + N * B * bpc * cfg_m.vocab_size * 4)                                        # Exp(1) noise
+        while args.lanes > 1 and args.lanes * per_chain > 180e9:
+            args.lanes -= 1
     pipe = SamplingPipeline(gpt, vq, lanes=args.lanes, steps_per_turn=args.steps_per_turn, vq_low_priority=args.vq_own_stream,
                             cu_partition=True if args.lane_cu_mask else None, vq_cus=args.vq_cus,
                             lanes_avoid_vq_cus=args.lanes_avoid_vq_cus, batches_per_chain=bpc,

@@ -55,20 +55,27 @@ def generate_iter(model, cond, max_new_tokens, emb_masks=None, cfg_scale=1.0, cf
     prefix = 1 if kind == "c2i" else cond.shape[1]          # conditioning positions in front of the image tokens
     prefilled = False
     if more_conds:
-        if kind != "c2i" or noise_seq is not None:
-            raise NotImplementedError("_more_conds: class-conditional chains without injected noise")
+        if noise_seq is not None:
+            raise NotImplementedError("_more_conds with injected noise: concatenate the batches and their noise yourself")
         n, groups = cond.shape[0], 1 + len(more_conds)
         model.setup_caches(max_batch_size=(2 if use_cfg else 1) * n * groups, max_seq_length=prefix + max_new_tokens,
                            dtype=model.tok_embeddings.weight.dtype)
-        parts = [cond]
+        parts, mask_parts = [cond], [emb_masks]
         for j in range(groups):
             if j > 0:
-                parts.append(more_conds[j - 1]() if callable(more_conds[j - 1]) else more_conds[j - 1])
-                if parts[-1].shape != cond.shape:
+                item = more_conds[j - 1]() if callable(more_conds[j - 1]) else more_conds[j - 1]
+                c_j, m_j = item if isinstance(item, tuple) else (item, None)   # text-conditional: (caption_embs, emb_masks)
+                if c_j.shape != cond.shape:
                     raise ValueError("batches that share a chain must have the same size")
+                parts.append(c_j)
+                mask_parts.append(m_j if m_j is not None else emb_masks)        # no own mask: the shared one (or none at all)
             if sample_logits:
                 model._engine.draw_noise(max_new_tokens, n * groups, j * n, n)
         cond = torch.cat(parts)
+        if any(m is not None for m in mask_parts):
+            if any(m is None for m in mask_parts):
+                raise ValueError("either every batch of a chain carries emb_masks or none does")
+            emb_masks = torch.cat(mask_parts)
         prefilled = bool(sample_logits)
     B = cond.shape[0]
     rows = torch.cat([cond, _null_condition(model, cond)]) if use_cfg else cond   # CFG: conditional rows, then their twins

@@ -122,9 +122,7 @@ class SamplingPipeline:
         # kernel, the weight stream of every GEMM) are paid once for twice the rows.  Measured on MI355X, GPT-L 384 px,
         # 32 images per batch: one chain in flight 47 -> 61-70 img/s, 3 chains in flight 76 -> 85+ (tools/exp_r2e.py).
         self.bpc = max(1, int(batches_per_chain))
-        if self.bpc > 1 and gpt.model_type != "c2i":
-            raise NotImplementedError("batches_per_chain > 1 is built for class-conditional models (per-batch caption masks "
-                                      "would have to be concatenated too)")
+        # (text-conditional batches may be given as (caption_embs, emb_masks) tuples: a chain concatenates both)
         # optional: one shared stream for every lane's VQ decode (see SamplingLane)
         self.vq_stream = torch.cuda.Stream(device=self.dev, priority=0) if (vq is not None and vq_low_priority) else None
         # experiment (bench.py --vq-cus N): the MFMA-bound decoder kernels fill the register file of every CU they run on
@@ -191,24 +189,31 @@ class SamplingPipeline:
                     # a callable is evaluated only now, so that a driver can draw its labels from the device generator in the
                     # reference's order (labels of batch i, noise of batch i, labels of batch i+1, ...: sample_c2i_ddp.py:128-140)
                     group = list(conds[nxt:nxt + self.bpc])
+
+                    def ev(c):  # a batch: tensor | (tensor, emb_masks) | callable returning either
+                        c = c() if callable(c) else c
+                        return c if isinstance(c, tuple) else (c, None)
+                    chain, mask0 = ev(group[0])
+                    rows = chain.shape[0]
+                    kw = gen_kw if mask0 is None else dict(gen_kw, emb_masks=mask0)
                     if self.bpc == 1:
-                        chain = group[0]() if callable(group[0]) else group[0]
-                        rows, kw = chain.shape[0], gen_kw
                         shape = decode_shape
                     else:
                         # the chain's first batch now; the others are evaluated by generate_iter in RNG order (labels of batch j,
                         # noise of batch j, labels of batch j + 1, ...).  A last, incomplete group repeats its last batch (rows
                         # computed and dropped): one chain shape per lane
-                        chain = group[0]() if callable(group[0]) else group[0]
-                        rows = chain.shape[0]
-                        more = group[1:] + [group[-1] if not callable(group[-1]) else (lambda c=chain: c)] * (self.bpc - len(group))
+                        pad = group[-1] if not callable(group[-1]) else (lambda c=(chain, mask0): c)
+                        more = group[1:] + [pad] * (self.bpc - len(group))
                         if "_noise_seq" in gen_kw:  # injected noise (tests): evaluate now, the whole chain's block is given
-                            parts = [chain] + [c() if callable(c) else c for c in more]
-                            if any(c.shape[0] != rows for c in parts):
+                            parts = [(chain, mask0)] + [ev(c) for c in more]
+                            if any(c.shape[0] != rows for c, _ in parts):
                                 raise ValueError("batches that share a chain must have the same size")
-                            chain, kw = torch.cat(parts), gen_kw
+                            chain = torch.cat([c for c, _ in parts])
+                            shared = gen_kw.get("emb_masks")
+                            if mask0 is not None or shared is not None:
+                                kw = dict(gen_kw, emb_masks=torch.cat([m if m is not None else shared for _, m in parts]))
                         else:
-                            kw = dict(gen_kw, _more_conds=more)
+                            kw = dict(kw, _more_conds=more)
                         shape = None if decode_shape is None else [rows * self.bpc] + list(decode_shape[1:])
                     lane.start((nxt, len(group), rows), chain, max_new_tokens, shape, kw)
                     nxt += len(group)

@@ -100,5 +100,15 @@ def test_chain_of_batches_draws_labels_and_noise_in_consecutive_generate_order()
     assert ev == [] and m._engine.call["rows"].tolist() == [1, 2, 3, 4] and "_noise_prefilled" not in m._engine.call["sp"]
     with pytest.raises(ValueError):
         generate(m, torch.tensor([1, 2]), 6, _more_conds=[torch.tensor([3, 4, 5])])
-    with pytest.raises(NotImplementedError):
-        generate(_model("t2i", 3), torch.zeros(2, 3, 4), 4, _more_conds=[torch.zeros(2, 3, 4)])
+    # text-conditional chains: captions and their masks are concatenated batch by batch (a batch without its own mask takes the shared one)
+    mt = _model("t2i", 3)
+    c0, c1 = torch.ones(2, 3, 4), 2 * torch.ones(2, 3, 4)
+    m0, m1 = torch.tensor([[0, 1, 1], [1, 1, 1]]), torch.tensor([[0, 0, 1], [0, 1, 1]])
+    generate(mt, c0, 4, emb_masks=m0, cfg_scale=7.5, _more_conds=[lambda: (c1, m1)])
+    c = mt._engine.call
+    assert tuple(c["rows"].shape) == (8, 3, 4) and torch.equal(c["rows"][:4], torch.cat([c0, c1]))
+    assert torch.equal(c["masks"], torch.cat([m0, m1, m0, m1])) and mt.caches == (8, 3 + 4, torch.bfloat16)
+    generate(mt, c0, 4, emb_masks=m0, cfg_scale=1.0, _more_conds=[c1])
+    assert torch.equal(mt._engine.call["masks"], torch.cat([m0, m0]))
+    with pytest.raises(ValueError):
+        generate(mt, c0, 4, cfg_scale=1.0, _more_conds=[(c1, m1)])

@@ -577,6 +577,49 @@ def test_pipeline_batches_per_chain_rows_are_independent():
         assert int(ids.min()) >= 0 and int(ids.max()) < 1024 and bool(torch.isfinite(img).all())
 
 
+def test_pipeline_text_conditional_batches_share_a_chain():
+    """Round 3: text-conditional batches (caption_embs, emb_masks) may share a decode chain too -- captions and masks are
+    concatenated, every batch comes out as its own generate() call does from the same noise (fp32, token for token), with the
+    seeded RNG order of consecutive generate() calls when the noise is drawn by the engine."""
+    from llamagen_amd import generate
+    from llamagen_amd.gpt import ModelArgs, Transformer
+    from llamagen_amd.pipeline import SamplingPipeline
+    from llamagen_amd.testing import synth_for_module
+    dev = _dev()
+    T, C = 120, 64
+    kw = dict(n_layer=2, n_head=4, dim=256, vocab_size=1024, block_size=16, cls_token_num=T, caption_dim=C, model_type="t2i")
+    m = Transformer(ModelArgs(**kw))
+    m.load_state_dict(synth_for_module(m, seed=2, lin_std=0.05), strict=False)
+    m = m.to(device=dev).eval()
+    skw = dict(cfg_scale=7.5, cfg_interval=-1, temperature=1.0, top_k=100, top_p=1.0, sample_logits=True)
+    B, N = 2, 16
+    g = torch.Generator().manual_seed(3)
+    batches = []
+    for i in range(3):
+        lens = torch.randint(1, T + 1, (B,), generator=g)
+        mk = (torch.arange(T).unsqueeze(0) >= (T - lens).unsqueeze(1)).to(torch.int64)
+        batches.append(((torch.randn(B, T, C, generator=g) * mk[:, :, None]).to(dev), mk.to(dev)))
+    noise = torch.empty(N, 2 * B, 1024).exponential_(1.0, generator=torch.Generator().manual_seed(6)).to(dev)
+    ref = [generate(m, c, N, emb_masks=k, _noise_seq=noise[:, i * B:(i + 1) * B].contiguous(), **skw).clone()
+           for i, (c, k) in enumerate(batches[:2])]
+    m._engine = None
+    out = SamplingPipeline(m, None, lanes=1, batches_per_chain=2).run(batches[:2], N, _noise_seq=noise, **skw)
+    torch.cuda.synchronize()
+    for r, (o, _) in zip(ref, out):
+        assert torch.equal(r, o)
+    # engine-drawn noise: a chain of two batches consumes the default generator like two consecutive generate() calls
+    m._engine = None
+    torch.manual_seed(17)
+    seq = [generate(m, c, N, emb_masks=k, **skw).clone() for c, k in batches]
+    m._engine = None
+    torch.manual_seed(17)
+    out = SamplingPipeline(m, None, lanes=1, batches_per_chain=2).run(batches, N, **skw)   # chain 0: batches 0, 1; chain 1: batch 2 + pad
+    torch.cuda.synchronize()
+    for r, (o, _) in zip(seq, out):
+        assert torch.equal(r, o)
+
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 def test_t2i_batched_prefill_matches_sequential(dt, monkeypatch):
     """The batched prefix prefill (all T caption positions per layer at once: lgen_rope_append_prefill,

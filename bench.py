@@ -562,16 +562,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # transparency: the same workload with ONE chain in flight (2 chains on lane 0), outside the timed region above
+    # transparency: the same workload with ONE chain in flight (2 chains, one after the other, on a lane of their own with the
+    # single-chain GEMM shapes), outside the timed region above
     chain1 = None
     if args.lanes > 1:
-        one = SamplingPipeline.__new__(SamplingPipeline)
-        one.dev, one.lanes, one.steps_per_turn, one.vq_stream, one.bpc = pipe.dev, pipe.lanes[:1], pipe.steps_per_turn, pipe.vq_stream, bpc
+        view = gpt.lane_view()
+        one = SamplingPipeline(view, vq, lanes=1, batches_per_chain=bpc)
+        one.prepare(B, N, **skw)
         fence()
         t1 = time.perf_counter()
         one.run([make_cond() for _ in range(2 * bpc)], N, **skw)
         fence()
         chain1 = B * world * 2 * bpc / (time.perf_counter() - t1)
+        del one, view
+        torch.cuda.empty_cache()
 
     if rank == 0:
         out = outs[-1]

@@ -185,6 +185,11 @@ class DecodeEngine:
         # Measured NEGATIVE on MI355X (+106 us per decode step: the extra line requests sit in front of the
         # kernel's own operand loads), so it is off; LGEN_PREFETCH=1 re-enables it for experiments.
         self.prefetch = os.environ.get("LGEN_PREFETCH", "0") == "1"
+        # workgroup shapes for chains that share the chip with two or more other chains (SamplingPipeline, lanes >= 3): <= 156 VGPRs
+        # and <= 64 KB of LDS per workgroup at 256 rows, so that a workgroup fits next to another kernel's.  Measured at 128 images per
+        # chain x 3 chains (tools/exp_r3e.py): decode only 111 -> 115.7 img/s, with the decoder 100.9 -> 101.7; alone the shapes cost
+        # ~2 us per layer (w1||w3 (2, 2, 8) x 6 passes: 14.4 us against (2, 4, 8) x 3: 12.6 us)
+        self.lean = bool(getattr(model, "_lean_gemms", False)) or os.environ.get("LGEN_LEAN") == "1"
         self.tile_override = {}      # kind ("qkv" | "wo" | "w13" | "w2" | "head") -> (mt, nt, kw)
         # tuning hook: LGEN_TILES="qkv=2,4,8;wo=4,1,8;w2=4,1,8" (e.g. fewer, fatter workgroups per GEMM so that the
         # kernels of several in-flight batches share the chip side by side instead of taking turns)
@@ -230,7 +235,8 @@ class DecodeEngine:
         self._graphs = {}
 
     def compatible(self, model, max_batch, S8, dtype) -> bool:
-        return (self.B2 == max_batch and self.S8 == S8 and self.dtype == dtype
+        lean = bool(getattr(model, "_lean_gemms", False)) or os.environ.get("LGEN_LEAN") == "1"
+        return (self.B2 == max_batch and self.S8 == S8 and self.dtype == dtype and self.lean == lean
                 and self.dev == model.tok_embeddings.weight.device and self._wsig == self._sig(model))
 
     def reset(self, max_batch: int):
@@ -250,6 +256,8 @@ class DecodeEngine:
         n-tiles (nt 2 / 4) only when there are >= 352 / 1024 of them (w1||w3, lm_head)."""
         if kind in self.tile_override:
             return self.tile_override[kind]
+        if self.lean and self.MTs >= 16 and self.fuse_norm and self.dtype == torch.bfloat16 and kind in ("w13", "wo", "w2"):
+            return {"w13": (2, 2, 8), "wo": (2, 1, 8), "w2": (2, 2, 8)}[kind]
         epi = {"qkv": L.EPI_QKV, "wo": L.EPI_RES, "w2": L.EPI_RES, "w13": L.EPI_SWIGLU, "head": L.EPI_ROWS}[kind]
         fused = self.fuse_norm and kind in ("qkv", "w13", "head")
         ntiles = N // 16

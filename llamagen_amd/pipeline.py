@@ -26,6 +26,13 @@ import torch
 from .generate import generate_iter
 
 
+def _eval_batch(c):
+    """One entry of SamplingPipeline.run(conds): a conditioning tensor, a (caption_embs, emb_masks) tuple, or a callable that
+    returns either (evaluated only when its chain starts: RNG order) -> (cond, emb_masks or None)."""
+    c = c() if callable(c) else c
+    return c if isinstance(c, tuple) else (c, None)
+
+
 def cu_mask_words(n_cu: int, part: int, parts: int) -> List[int]:
     """32-bit mask words selecting the `part`-th of `parts` contiguous slices of CU bits 0..n_cu-1.  On multi-XCD
     parts the kernel driver is understood to deal consecutive mask bits round-robin over the XCDs, in which case a
@@ -158,6 +165,10 @@ class SamplingPipeline:
         self.cu_partition = bool(cu_partition and lanes > 1)
         self.lanes: List[SamplingLane] = [SamplingLane(gpt, vq, stream=streams[i], primary=(i == 0), vq_stream=self.vq_stream,
                                                        vq_chunk=vq_chunk) for i in range(lanes)]
+        # three or more chains in flight: the engines pick GEMM workgroup shapes with a smaller register / LDS footprint (they
+        # co-reside with the other chains' kernels; engine.DecodeEngine.lean), a little slower alone, faster together
+        for lane in self.lanes:
+            lane.gpt._lean_gemms = lanes >= 3
         self.steps_per_turn = steps_per_turn
 
     def prepare(self, batch: int, max_new_tokens: int, **gen_kw):
@@ -189,10 +200,7 @@ class SamplingPipeline:
                     # a callable is evaluated only now, so that a driver can draw its labels from the device generator in the
                     # reference's order (labels of batch i, noise of batch i, labels of batch i+1, ...: sample_c2i_ddp.py:128-140)
                     group = list(conds[nxt:nxt + self.bpc])
-
-                    def ev(c):  # a batch: tensor | (tensor, emb_masks) | callable returning either
-                        c = c() if callable(c) else c
-                        return c if isinstance(c, tuple) else (c, None)
+                    ev = _eval_batch
                     chain, mask0 = ev(group[0])
                     rows = chain.shape[0]
                     kw = gen_kw if mask0 is None else dict(gen_kw, emb_masks=mask0)

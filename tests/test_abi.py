@@ -120,22 +120,24 @@ def test_tile_heuristics_are_valid_for_every_registry_model(lib):
                 kch = d // kc
                 for fuse in (False, True):
                     fuse = fuse and dtype == L.BF16 and kch % 8 == 0 and 3 <= kch // 8 <= 6
-                    eng = types.SimpleNamespace(tile_override={}, pass_override={}, fuse_norm=fuse, mt=min(mts, 4), MTs=mts, kc=kc, lib=lib)
-                    for kind, N, K, epi in (("qkv", 3 * d, d, None), ("wo", d, d, L.EPI_RES), ("w13", 2 * F, d, L.EPI_SWIGLU),
-                                            ("w2", d, F, L.EPI_RES), ("head", 16384, d, L.EPI_ROWS)):
-                        mt, nt, kw = DecodeEngine._tiles(eng, kind, N, K)
-                        nw = 8 if (fuse and kind in ("qkv", "w13", "head")) else 0
-                        passes, db = DecodeEngine._passes(eng, kind, N, (mt, nt, kw))   # round 3: n-groups per workgroup
-                        assert passes >= 1 and (passes == 1 or nw), (kind, passes)
-                        if passes > 1:
-                            assert lib.lgen_gemm_schedule_hint(passes, db) == 0
-                        if kind == "qkv":
-                            rc = lib.lgen_gemm_qkv_rope(8, 8, 8, 8, 8, 8, 8, B2, mts, d, H, d // H, 64 if d // H <= 64 else 128, 584, 0,
-                                                        dtype, mt, nt, kw, nw, 8 if nw else 0, kch, 1e-5, 0)
-                        else:
-                            rc = lib.lgen_gemm(8, 8, 8, B2, mts, N, K, epi, dtype, mt, nt, kw, nw, 8 if nw else 0, kch, 1e-5, 0, 0)
-                        if rc in (-1, -2):
-                            bad.append((name, dtype, B2, fuse, kind, (mt, nt, kw), rc))
+                    for lean in (False, True):   # lean: the shapes SamplingPipeline asks for with >= 3 chains in flight
+                        eng = types.SimpleNamespace(tile_override={}, pass_override={}, fuse_norm=fuse, mt=min(mts, 4), MTs=mts, kc=kc,
+                                                    lib=lib, lean=lean, dtype=torch.bfloat16 if dtype == L.BF16 else torch.float32)
+                        for kind, N, K, epi in (("qkv", 3 * d, d, None), ("wo", d, d, L.EPI_RES), ("w13", 2 * F, d, L.EPI_SWIGLU),
+                                                ("w2", d, F, L.EPI_RES), ("head", 16384, d, L.EPI_ROWS)):
+                            mt, nt, kw = DecodeEngine._tiles(eng, kind, N, K)
+                            nw = 8 if (fuse and kind in ("qkv", "w13", "head")) else 0
+                            passes, db = DecodeEngine._passes(eng, kind, N, (mt, nt, kw))   # round 3: n-groups per workgroup
+                            assert passes >= 1 and (passes == 1 or nw), (kind, passes)
+                            if passes > 1:
+                                assert lib.lgen_gemm_schedule_hint(passes, db) == 0
+                            if kind == "qkv":
+                                rc = lib.lgen_gemm_qkv_rope(8, 8, 8, 8, 8, 8, 8, B2, mts, d, H, d // H, 64 if d // H <= 64 else 128, 584, 0,
+                                                            dtype, mt, nt, kw, nw, 8 if nw else 0, kch, 1e-5, 0)
+                            else:
+                                rc = lib.lgen_gemm(8, 8, 8, B2, mts, N, K, epi, dtype, mt, nt, kw, nw, 8 if nw else 0, kch, 1e-5, 0, 0)
+                            if rc in (-1, -2):
+                                bad.append((name, dtype, B2, fuse, lean, kind, (mt, nt, kw), rc))
     assert not bad, bad[:10]
 
 

@@ -18,13 +18,20 @@ the first image token sampled there), its K/V slots 0..T-1 and its mask rows are
 the step batch at position T -- the per-request prefill of the vLLM fork (serve/model_runner.py:982-1076) without stalling the
 other slots' graph replays for longer than that one prefill.
 
+Slot-count buckets (`slot_buckets=(16, 32)` next to `slots=64`; the captured-batch-size ladder of serve/model_runner.py:36-41):
+one engine + one captured graph per bucket, built on first use.  Before a step the batcher picks the smallest bucket that holds
+the live requests (running + queued); growing is immediate, shrinking waits `shrink_after` steps.  A switch moves every running
+request -- its K/V rows, token, position, class id and mask rows, and (when its slot index changes) its noise block and token row
+-- into the new bucket's rows with stream-ordered device copies, so a lightly loaded server replays a 32-row graph instead of a
+128-row one and still never recomputes a prefix.
+
 Every request produces exactly the tokens a batch-of-one `generate()` would with the same noise: rows are independent
 through every kernel (tests/test_gpu_serve.py holds that to the oracle, token for token, in fp32).
 """
 from __future__ import annotations
 
 import collections
-from typing import Dict, List, Optional
+from typing import Dict, List, Optional, Sequence
 
 import torch
 
@@ -33,9 +40,54 @@ from .engine import DecodeEngine
 from .gpt import find_multiple
 
 
+def bucket_ladder(slots: int, slot_buckets: Optional[Sequence[int]]) -> List[int]:
+    """Ascending captured slot counts; the full `slots` is always the last one."""
+    if slots < 1:
+        raise ValueError("slots must be >= 1")
+    sizes = sorted({int(b) for b in (slot_buckets or ())})
+    if sizes and (sizes[0] < 1 or sizes[-1] > slots):
+        raise ValueError(f"slot_buckets must lie in [1, {slots}]")
+    return [b for b in sizes if b < slots] + [slots]
+
+
+def pick_bucket(sizes: Sequence[int], live: int) -> int:
+    """Smallest captured slot count that holds `live` requests (the largest when none does)."""
+    for b in sizes:
+        if b >= live:
+            return b
+    return sizes[-1]
+
+
+def plan_moves(active: Sequence[bool], new_slots: int):
+    """(old slot, new slot) for every running request when the slot count becomes `new_slots`: a request keeps its index when
+    that still exists, otherwise it takes the lowest free one."""
+    run = [s for s, a in enumerate(active) if a]
+    if len(run) > new_slots:
+        raise ValueError(f"{len(run)} running requests do not fit {new_slots} slots")
+    free = [t for t in range(new_slots) if not (t < len(active) and active[t])]
+    return [(s, s) if s < new_slots else (s, free.pop(0)) for s in run]
+
+
+class _Bucket:
+    """One captured slot count: its engine (KV rows, activations), per-row positions / class ids and its step graph."""
+
+    def __init__(self, model, slots: int, use_cfg: bool, S8: int, dtype, dev):
+        self.B = slots
+        self.B2 = 2 * slots if use_cfg else slots
+        self.eng = e = DecodeEngine(model, self.B2, S8, dtype)
+        R = e.MTs * 16
+        # parked rows sit at position 1: a valid slot that is not 0 (= "fresh class-conditional request" for lgen_embed_rows) and
+        # costs the attention two keys per idle row instead of a full sequence
+        self.row_pos = torch.full((R,), 1, dtype=torch.int32, device=dev)
+        self.cond = torch.full((R,), int(model.num_classes), dtype=torch.int32, device=dev)   # uncond rows: the null class
+        e.pos_rows = self.row_pos  # switches the engine's layer chain to the per-row entry points
+        self.graph = None
+
+
 class ContinuousBatcher:
     def __init__(self, model, slots: int, max_new_tokens: int, cfg_scale: float = 1.0, cfg_interval: int = -1,
-                 temperature: float = 1.0, top_k: int = 0, top_p: float = 1.0, sample_logits: bool = True):
+                 temperature: float = 1.0, top_k: int = 0, top_p: float = 1.0, sample_logits: bool = True,
+                 slot_buckets: Optional[Sequence[int]] = None, shrink_after: int = 8):
         if model.model_type not in ("c2i", "t2i"):
             raise Exception("please check model type")
         dev = model.tok_embeddings.weight.device
@@ -45,33 +97,85 @@ class ContinuousBatcher:
         self.num_classes, self.V = int(model.num_classes), int(model.config.vocab_size)
         self.t2i = model.model_type == "t2i"
         self.T = int(model.cls_token_num) if self.t2i else 1
-        self.B, self.N = slots, max_new_tokens
+        self.slots, self.N = int(slots), max_new_tokens
         self.use_cfg = cfg_scale > 1.0
-        self.B2 = 2 * slots if self.use_cfg else slots
-        dtype = model.tok_embeddings.weight.dtype
+        self._dtype = model.tok_embeddings.weight.dtype
         self.S8 = find_multiple(self.T + max_new_tokens, 8)
         if max_new_tokens > model.block_size:
             raise IndexError(f"{max_new_tokens} tokens exceed block_size {model.block_size}")
-        self.eng = DecodeEngine(model, self.B2, self.S8, dtype)
-        e = self.eng
-        R = e.MTs * 16
-        # parked rows sit at position 1: a valid slot that is not 0 (= "fresh class-conditional request" for lgen_embed_rows) and
-        # costs the attention two keys per idle row instead of a full sequence
-        self.row_pos = torch.full((R,), 1, dtype=torch.int32, device=dev)
+        self.bucket_sizes = bucket_ladder(self.slots, slot_buckets)
+        self.shrink_after = max(1, int(shrink_after))
+        self._buckets: Dict[int, _Bucket] = {}
+        self._shrink_wait = 0
+        self.switches = 0
+        self.cur = self._bucket(self.bucket_sizes[0] if len(self.bucket_sizes) > 1 else self.slots)
+        # slot-indexed state shared by every bucket (bucket k uses slots 0 .. k-1)
         self.row_step = torch.full((slots,), max_new_tokens, dtype=torch.int32, device=dev)  # >= N: empty slot
-        self.cond = torch.full((R,), model.num_classes, dtype=torch.int32, device=dev)      # uncond rows: the null class
-        self.noise = torch.empty(slots, max_new_tokens, e.V, dtype=torch.float32, device=dev) if sample_logits else None
+        self.noise = torch.empty(slots, max_new_tokens, self.V, dtype=torch.float32, device=dev) if sample_logits else None
         self.seq = torch.zeros(slots, max_new_tokens, dtype=torch.int32, device=dev)
         self.sp = dict(cfg_scale=float(cfg_scale), cfg_interval=int(cfg_interval), temperature=float(temperature), top_k=int(top_k),
                        top_p=float(top_p), greedy=0 if sample_logits else 1)
-        e.pos_rows = self.row_pos  # switches the engine's layer chain to the per-row entry points
         self._pe = None             # t2i: the private prefill engine (built on the first caption request)
-        self._graph = None
         self._queue = collections.deque()
         self._slot_req: List[Optional[int]] = [None] * slots
         self._slot_left = [0] * slots
         self._next_id = 0
         self.steps_run = 0
+
+    # the bucket in use: rows b and B + b pair up, so B is the CURRENT bucket's slot count
+    B = property(lambda self: self.cur.B)
+    B2 = property(lambda self: self.cur.B2)
+    eng = property(lambda self: self.cur.eng)
+    row_pos = property(lambda self: self.cur.row_pos)
+    cond = property(lambda self: self.cur.cond)
+
+    def _bucket(self, size: int) -> _Bucket:
+        if size not in self._buckets:
+            self._buckets[size] = _Bucket(self.model, size, self.use_cfg, self.S8, self._dtype, self.dev)
+        return self._buckets[size]
+
+    # ---- bucket choice and migration --------------------------------------------------------------------------------------
+    def _live(self) -> int:
+        return sum(r is not None for r in self._slot_req) + len(self._queue)
+
+    def _choose(self):
+        """Grow at once when the live requests do not fit, shrink after `shrink_after` consecutive steps in which they would."""
+        want = pick_bucket(self.bucket_sizes, self._live())
+        if want > self.cur.B:
+            self._switch(self._bucket(want))
+        elif want < self.cur.B:
+            self._shrink_wait += 1
+            if self._shrink_wait >= self.shrink_after:
+                self._switch(self._bucket(want))
+        else:
+            self._shrink_wait = 0
+
+    def _switch(self, nb: _Bucket):
+        """Move every running request from the current bucket's rows into `nb`'s (stream-ordered device copies)."""
+        ob = self.cur
+        moves = plan_moves([r is not None for r in self._slot_req], nb.B)
+        oe, ne = ob.eng, nb.eng
+        for s, t in moves:
+            for src, dst in ((s, t),) + (((ob.B + s, nb.B + t),) if self.use_cfg else ()):
+                ne.k_cache[:, dst].copy_(oe.k_cache[:, src])
+                ne.v_cache[:, dst].copy_(oe.v_cache[:, src])
+                ne.cur_tok[dst:dst + 1].copy_(oe.cur_tok[src:src + 1])
+                nb.row_pos[dst:dst + 1].copy_(ob.row_pos[src:src + 1])
+                nb.cond[dst:dst + 1].copy_(ob.cond[src:src + 1])
+                if self.t2i:
+                    ne.causal_mask[dst].copy_(oe.causal_mask[src])
+            if t != s:
+                if self.noise is not None:
+                    self.noise[t].copy_(self.noise[s])
+                self.seq[t].copy_(self.seq[s])
+                self.row_step[t:t + 1].copy_(self.row_step[s:s + 1])
+                self.row_step[s] = self.N
+                self._slot_req[t], self._slot_left[t] = self._slot_req[s], self._slot_left[s]
+                self._slot_req[s], self._slot_left[s] = None, 0
+        ob.row_pos.fill_(1)  # the old bucket's rows idle until it is used again
+        self.cur = nb
+        self._shrink_wait = 0
+        self.switches += 1
 
     # ---- requests ---------------------------------------------------------------------------------------------------
     def submit(self, class_label, noise: Optional[torch.Tensor] = None, emb_mask: Optional[torch.Tensor] = None) -> int:
@@ -172,11 +276,13 @@ class ContinuousBatcher:
         done: Dict[int, torch.Tensor] = {}
         with torch.no_grad():
             while self._queue or any(r is not None for r in self._slot_req):
+                if len(self.bucket_sizes) > 1:
+                    self._choose()
                 for b in range(self.B):  # refill free slots (arrival order)
                     if self._slot_req[b] is None and self._queue:
                         self._load(b, *self._queue.popleft())
                 if use_graph:
-                    if self._graph is None:
+                    if self.cur.graph is None:
                         self._step()  # warm every kernel once, eagerly
                         self.steps_run += 1
                         self._account(done)
@@ -184,9 +290,9 @@ class ContinuousBatcher:
                         torch.cuda.synchronize()
                         with torch.cuda.graph(g):
                             self._step()
-                        self._graph = g
+                        self.cur.graph = g
                         continue
-                    self._graph.replay()
+                    self.cur.graph.replay()
                 else:
                     self._step()
                 self.steps_run += 1
@@ -201,3 +307,6 @@ class ContinuousBatcher:
             if self._slot_left[b] == 0:  # the step just enqueued wrote this request's last token
                 done[self._slot_req[b]] = self.seq[b].clone()
                 self._slot_req[b] = None
+                self.row_pos[b] = 1          # park the rows again (after that step, stream-ordered): an idle row at its final
+                if self.use_cfg:             # position would keep costing the attention a full sequence
+                    self.row_pos[self.B + b] = 1

@@ -115,3 +115,67 @@ def test_text_conditional_requests_with_staggered_arrivals(cfg_scale, slots):
         np.testing.assert_array_equal(out[rid].cpu().numpy(), ref[0].numpy(), err_msg=f"request {rid}")
     with pytest.raises(ValueError):
         cb.submit(torch.zeros(T - 1, C))
+
+
+@pytest.mark.parametrize("kind,cfg_scale", [("c2i", 4.0), ("c2i", 1.0), ("t2i", 7.5)])
+def test_slot_count_buckets_move_running_requests_between_graphs(kind, cfg_scale):
+    """Captured slot counts 1 / 2 / 6: one request starts alone in the 1-slot graph, a burst grows the batch mid-sequence, the tail
+    shrinks it again (requests relocated to low slots mid-sequence).  Whatever graphs a request passed through, its tokens are the
+    oracle's batch-of-one generate() on its noise (fp32 storage)."""
+    from llamagen_amd.serve import ContinuousBatcher
+    kw = KW if kind == "c2i" else KW_T2I
+    m = Transformer(ModelArgs(**kw))
+    sd = synth_for_module(m, seed=3, lin_std=0.05)
+    m.load_state_dict(sd, strict=False)
+    m = m.to(device=torch.device("cuda:0"), dtype=torch.float32).eval()
+    N, V, nreq = 16, kw["vocab_size"], 9
+    g = torch.Generator().manual_seed(31)
+    if kind == "c2i":
+        conds = [(int(torch.randint(0, 10, (1,), generator=g)), None) for _ in range(nreq)]
+    else:
+        T, C = 120, 64
+        conds = []
+        for _ in range(nreq):
+            n = int(torch.randint(1, T + 1, (1,), generator=g))
+            mk = torch.zeros(T, dtype=torch.int64)
+            mk[T - n:] = 1
+            conds.append((torch.randn(T, C, generator=g) * mk[:, None], mk))
+    noises = [torch.empty(N, V).exponential_(1, generator=g) for _ in range(nreq)]
+    skw = dict(cfg_scale=cfg_scale, cfg_interval=-1, temperature=1.0, top_k=100, top_p=1.0, sample_logits=True)
+    cb = ContinuousBatcher(m, 6, N, slot_buckets=(1, 2), shrink_after=2, **skw)
+    assert cb.bucket_sizes == [1, 2, 6] and cb.B == 1
+    sub = lambda i: cb.submit(conds[i][0], noises[i], conds[i][1]) if kind == "t2i" else cb.submit(conds[i][0], noises[i])
+    ids, out = [sub(0)], {}
+    cb._load(0, *cb._queue.popleft())
+    for _ in range(3):                                   # alone in the 1-slot bucket (eager steps)
+        cb._step()
+        cb.steps_run += 1
+        cb._account(out)
+    ids += [sub(i) for i in range(1, 6)]
+    for _ in range(7):                                   # 6 live: the 6-slot bucket; stop mid-sequence
+        cb._choose()
+        for b in range(cb.B):
+            if cb._slot_req[b] is None and cb._queue:
+                cb._load(b, *cb._queue.popleft())
+        cb._step()
+        cb.steps_run += 1
+        cb._account(out)
+    assert cb.B == 6
+    out.update(cb.run())                                 # graphs from here on; request 0 ends first, the rest together
+    ids += [sub(i) for i in range(6, 8)]
+    cb._load(4, *cb._queue.popleft())                    # placed in HIGH slots of the 6-slot bucket: the shrink to 2 slots two steps
+    cb._load(5, *cb._queue.popleft())                    # later relocates them (K/V rows, noise block, token row) to slots 0 and 1
+    out.update(cb.run())
+    assert cb.B == 2
+    ids.append(sub(8))
+    out.update(cb.run())                                 # 1 live -> 1 slot
+    torch.cuda.synchronize()
+    assert sorted(out) == ids and cb.B == 1 and cb.switches >= 3
+    model = O.GPTOracle(O.GPTConfig(**kw), sd, torch.float32)
+    for rid, (c, mk), nz in zip(ids, conds, noises):
+        it = iter(nz)
+        if kind == "c2i":
+            ref = O.generate(model, torch.tensor([c]), N, noise_fn=lambda shape: next(it).view(1, -1), **skw)
+        else:
+            ref = O.generate(model, c.unsqueeze(0), N, emb_masks=mk.unsqueeze(0), noise_fn=lambda shape: next(it).view(1, -1), **skw)
+        np.testing.assert_array_equal(out[rid].cpu().numpy(), ref[0].numpy(), err_msg=f"request {rid}")

@@ -22,6 +22,9 @@
 // no atomics).  Weight loads use the default cache policy (lanes a few layers apart share the stream in the
 // memory-side cache: 69.4 vs 65.7 img/s against non-temporal loads with 3 lanes, no difference with one).  Everything an epilogue
 // needs from memory (residual tile, RoPE angles) is requested before the main loop.
+#include <cstdlib>
+#include <type_traits>
+
 #include "lgen_common.h"
 #include "../../include/lgen.h"
 
@@ -195,6 +198,155 @@ __global__ __launch_bounds__((gemm_max_threads<MT, NT, NORM, EPI>())) void gemm_
     }
 }
 
+// ---- steady-state form for wide models (round 3) ---------------------------------------------------------------------
+// Same operation, same wave partition and the same chunk order per wave as gemm_kernel<..., NORM = false> -- bit-identical
+// results -- for K ranges that are long and uniform: every wave owns KCH / KW chunks (exact) and at least 2 * DEPTH of them
+// (d = 3200, F = 8704: GPT-3B; F = 4096: GPT-XXL's w2).  What changes is what the compiler can prove about the request queue.
+// In gemm_kernel the ring is filled under `if (k0 + s < k1)` and the loop may run zero times; with a conditional load in front
+// of the loop the number of requests YOUNGER than a stage's loads is unknown at the loop head, so the head waits for
+// vmcnt(0) -- all refills of the previous round -- and the scheduler then gathers the MFMAs of all stages behind that one
+// wait: load-all / wait-all, the steady state measured in round 2 (ISA: s_waitcnt vmcnt(3) .. vmcnt(0) at the loop head,
+// 200-340 TFLOP/s on GPT-3B's GEMMs).  Here the epilogue's operands are requested FIRST (older requests do not disturb the
+// count), the ring fill is unconditional, the loop is do-while, and a sched_barrier after each stage keeps the stage order, so
+// the waits become vmcnt((DEPTH - 1) * loads per stage): DEPTH - 1 stages stay in flight under the MFMAs of the oldest.
+template <typename D, int MT, int NT, int EPI, int DEPTH>
+__global__ __launch_bounds__((gemm_max_threads<MT, NT, false, EPI>())) void gemm_steady_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float4 red[];
+    constexpr int TILES = NT * MT;
+    constexpr int UNITS = EPI == EPI_SWIGLU ? (TILES / 2 > 0 ? TILES / 2 : 1) : TILES;
+    constexpr int UPW = (UNITS + 1) / 2;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int KW = blockDim.x >> 6;
+    const int nt0 = blockIdx.x * NT;
+    const int mt0 = blockIdx.y * MT;
+    const int cpw = a.KCH / KW;  // exact, >= 2 * DEPTH (launcher)
+    const int k0 = w * cpw, k1 = k0 + cpw;
+    int posr[MT];
+    load_row_pos<MT, EPI>(a, mt0, lane, posr);
+
+    const uint4* wbase = a.wp + ((size_t)nt0 * a.KCH) * 64 + lane;
+    const uint4* xbase = a.xp + (size_t)mt0 * 64 + lane;
+    const size_t wstride = (size_t)a.KCH * 64;
+    const size_t xstride = (size_t)a.MTs * 64;
+
+    // the epilogue's operands first
+    uint4 aux[UNITS];
+#pragma unroll
+    for (int q = 0; q < UNITS; ++q) aux[q] = make_uint4(0, 0, 0, 0);
+    if constexpr (epi_has_aux<EPI>()) {
+#pragma unroll
+        for (int q = 0; q < UNITS; ++q) {
+            const int u = w + q * KW;
+            if (u < UNITS) {
+                const int j = u / MT, i = u - j * MT;
+                aux[q] = epi_prefetch<D, EPI>(a, nt0 + j, mt0 + i, lane, pick_pos<MT>(posr, i));
+            }
+        }
+    }
+    uint4 A[DEPTH][NT], B[DEPTH][MT];
+#define LGEN_LOAD(s, kk)                                                                                  \
+    {                                                                                                     \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j) A[s][j] = ldg_w(wbase + j * wstride + (size_t)(kk) * 64); \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i) B[s][i] = xbase[(size_t)(kk) * xstride + i * 64];  \
+    }
+#define LGEN_MMA(s)                                                                                       \
+    {                                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                    \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j) acc[j][i] = D::mma(A[s][j], B[s][i], acc[j][i]); \
+    }
+#pragma unroll
+    for (int s = 0; s < DEPTH; ++s) LGEN_LOAD(s, k0 + s);
+
+    f32x4_t acc[NT][MT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    int k = k0;
+    do {
+#pragma unroll
+        for (int s = 0; s < DEPTH; ++s) {
+            LGEN_MMA(s);
+            LGEN_LOAD(s, k + s + DEPTH);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        k += DEPTH;
+    } while (k + 2 * DEPTH <= k1);
+#pragma unroll
+    for (int s = 0; s < DEPTH; ++s) {
+        if (k + s < k1) {
+            LGEN_MMA(s);
+            if (k + s + DEPTH < k1) LGEN_LOAD(s, k + s + DEPTH);
+        }
+    }
+    k += DEPTH;
+#pragma unroll
+    for (int s = 0; s < DEPTH; ++s)
+        if (k + s < k1) LGEN_MMA(s);
+#undef LGEN_LOAD
+#undef LGEN_MMA
+
+    if (KW == 1) {
+#pragma unroll
+        for (int q = 0; q < UNITS; ++q) {
+            if constexpr (EPI == EPI_SWIGLU) {
+                const int jp = q / MT, i = q - jp * MT;
+                epilogue<D, EPI>(a, nt0 + 2 * jp, mt0 + i, lane, acc[2 * jp][i], acc[(2 * jp + 1) % NT][i], aux[q], pick_pos<MT>(posr, i));
+            } else {
+                const int j = q / MT, i = q - j * MT;
+                epilogue<D, EPI>(a, nt0 + j, mt0 + i, lane, acc[j][i], acc[j][i], aux[q], pick_pos<MT>(posr, i));
+            }
+        }
+        return;
+    }
+    // cross-wave K reduction through LDS, fixed summation order (wave 0, 1, 2, ...), as in gemm_kernel
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            f32x4_t v = acc[j][i];
+            red[((size_t)w * TILES + j * MT + i) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    __syncthreads();
+    auto rsum = [&](int t) {
+        float4 s = red[(size_t)t * 64 + lane];
+        for (int ww = 1; ww < KW; ++ww) {
+            float4 p = red[((size_t)ww * TILES + t) * 64 + lane];
+            s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+        }
+        return f32x4_t{s.x, s.y, s.z, s.w};
+    };
+#pragma unroll
+    for (int q = 0; q < UPW; ++q) {
+        const int u = w + q * KW;
+        if (u < UNITS) {
+            if constexpr (EPI == EPI_SWIGLU) {
+                const int jp = u / MT, i = u - jp * MT;
+                epilogue<D, EPI>(a, nt0 + 2 * jp, mt0 + i, lane, rsum((2 * jp) * MT + i), rsum((2 * jp + 1) * MT + i), aux[q], pick_pos<MT>(posr, i));
+            } else {
+                const int j = u / MT, i = u - j * MT;
+                const f32x4_t v = rsum(u);
+                epilogue<D, EPI>(a, nt0 + j, mt0 + i, lane, v, v, aux[q], pick_pos<MT>(posr, i));
+            }
+        }
+    }
+}
+
+// tile shapes with a steady-state instantiation: the ones the host heuristics can pick for wide models at 128 / 256 rows
+template <typename D, int MT, int NT, int EPI, bool NORM>
+constexpr bool gemm_has_steady() {
+    return std::is_same<D, BF16>::value && !NORM && (EPI == EPI_RES || EPI == EPI_SWIGLU || EPI == EPI_QKV || EPI == EPI_ROWS) &&
+           ((MT == 4 && (NT == 1 || NT == 2 || NT == 4)) || (MT == 2 && (NT == 2 || NT == 4)) || (MT == 8 && (NT == 1 || NT == 2)));
+}
+
+// LGEN_GEMM_STEADY=0 keeps the generic form (the parity test compares the two; read at launch = capture time)
+static bool steady_enabled() {
+    const char* e = getenv("LGEN_GEMM_STEADY");
+    return !(e && e[0] == '0');
+}
+
 // ring-buffer shapes whose operand set does not fit 256 VGPRs (they would spill; csrc/gemm_skinny.usage): refused, not compiled
 template <int MT, int NT, int EPI, bool NORM>
 constexpr bool gemm_spills() { return NORM && (MT == 8 || (MT == 4 && NT == 4 && EPI == EPI_QKV)); }
@@ -208,6 +360,18 @@ static int launch(const GemmArgs& a, int kw, hipStream_t st) {
     dim3 grid((a.N / 16) / NT, a.MTs / MT);
     size_t lds = kw > 1 ? (size_t)kw * NT * MT * 64 * sizeof(float4) : 0;
     if (lds > 160 * 1024 || kw * 64 > gemm_max_threads<MT, NT, NORM, EPI>()) return LGEN_ERR_BAD_ARG;
+    if constexpr (gemm_has_steady<D, MT, NT, EPI, NORM>()) {
+        if (a.KCH % kw == 0 && a.KCH / kw >= 2 * DEPTH && steady_enabled()) {
+            if (lds > 64 * 1024) {
+                hipError_t e = hipFuncSetAttribute((const void*)gemm_steady_kernel<D, MT, NT, EPI, DEPTH>,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return (int)e;
+            }
+            hipLaunchKernelGGL((gemm_steady_kernel<D, MT, NT, EPI, DEPTH>), grid, dim3(64 * kw), lds, st, a);
+            LGEN_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<D, MT, NT, EPI, NORM, DEPTH>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -256,12 +256,33 @@ class DecodeEngine:
         n-tiles (nt 2 / 4) only when there are >= 352 / 1024 of them (w1||w3, lm_head)."""
         if kind in self.tile_override:
             return self.tile_override[kind]
-        if self.lean and self.MTs >= 16 and self.fuse_norm and self.dtype == torch.bfloat16 and kind in ("w13", "wo", "w2"):
-            return {"w13": (2, 2, 8), "wo": (2, 1, 8), "w2": (2, 2, 8)}[kind]
-        epi = {"qkv": L.EPI_QKV, "wo": L.EPI_RES, "w2": L.EPI_RES, "w13": L.EPI_SWIGLU, "head": L.EPI_ROWS}[kind]
-        fused = self.fuse_norm and kind in ("qkv", "w13", "head")
         ntiles = N // 16
         kch = K // self.kc
+        bf16 = self.dtype == torch.bfloat16
+        if self.lean and self.MTs >= 16 and self.fuse_norm and bf16 and kind in ("w13", "wo", "w2"):
+            return {"w13": (2, 2, 8), "wo": (2, 2, 4) if (ntiles >= 96 and kch // 4 >= 12) else (2, 1, 8),
+                    "w2": (2, 2, 4 if kch // 4 >= 12 else 8)}[kind]
+        if self.MTs >= 16 and bf16 and not self.fuse_norm and kch >= 96:
+            # wide models (GPT-3B: d 3200, F 8704) at 256 rows: every GEMM is the plain ring kernel and the work is MFMA-shaped
+            # (64 GFLOP per layer), so big tiles and FEW K-splitting waves win -- measured (tools/gemm_sweep_wide.py,
+            # profiles/r03_wide_sweep.log): qkv (4, 4, 4) 45.0 us against (4, 2, 8) 54.7, wo (4, 4, 4) 18.2 / 26.9, w1||w3 (8, 2, 4)
+            # 64.4 / 84.1, w2 (4, 4, 8) 40.1 / 66.6, lm_head (8, 2, 4) 47.5 / 68.4: 4.07 ms of GEMMs per decode step instead of 5.64
+            mt, nt = {"qkv": (4, 4), "wo": (4, 4), "w13": (8, 2), "w2": (4, 4), "head": (8, 2)}[kind]
+            while ntiles % nt:
+                nt //= 2
+            while self.MTs % mt:
+                mt //= 2
+            if kind == "w13":
+                nt = max(nt, 2)
+            return mt, nt, (4 if kch <= 128 else 8)
+        if self.MTs >= 16 and bf16 and self.fuse_norm and kch // 4 >= 12 and (kind == "w2" or (kind == "wo" and ntiles >= 96)) \
+                and ntiles % 2 == 0:
+            # RES GEMMs of the fused-norm models at 256 rows: 4 waves x >= 12 chunks run the steady-state ring kernel (counted waits);
+            # measured: GPT-L w2 (2, 2, 4) 6.16 us against (4, 1, 8) 7.35 / (2, 2, 8) 6.90; GPT-XXL w2 13.2 / 17.1, wo 5.6 / 8.1
+            # (GPT-L's wo, 8 chunks per wave at kw 4, stays (4, 1, 8): 4.64 us)
+            return 2, 2, 4
+        epi = {"qkv": L.EPI_QKV, "wo": L.EPI_RES, "w2": L.EPI_RES, "w13": L.EPI_SWIGLU, "head": L.EPI_ROWS}[kind]
+        fused = self.fuse_norm and kind in ("qkv", "w13", "head")
         if fused and kch % 8 == 0 and 3 <= kch // 8 <= 6:
             # normpre kernel (persistent along N since round 3): every workgroup normalises its own rows of the panel once and
             # walks `_passes` n-groups, so few rows per workgroup and 4 n-tiles per group.  Measured best (tools/gemm_sweep.py,

@@ -140,6 +140,49 @@ def test_gemm_swiglu(dt, M, F, K, tiles):
     _close(unpack_act(out, M), ref, dt, "swiglu", frac_ulp1=0.05, ulps=3)  # product of two independently flipping factors
 
 
+@pytest.mark.parametrize("M,N,K,tiles", [(256, 3200, 3200, (4, 1, 5)), (256, 1024, 3200, (8, 2, 5)), (128, 512, 8704, (4, 2, 8)),
+                                         (256, 2048, 3200, (4, 4, 4)), (200, 512, 8704, (2, 4, 8)), (256, 1024, 3200, (2, 2, 5)),
+                                         (128, 1024, 4096, (8, 1, 8))])
+def test_gemm_steady_state_form_is_bit_identical(M, N, K, tiles, monkeypatch):
+    """Wide-model K ranges (d 3200, F 8704: every wave owns >= 12 chunks): the steady-state ring kernel (counted waits, round 3)
+    keeps the generic kernel's wave partition and chunk order, so rows / residual (+ RMSNorm statistics) / SwiGLU outputs must be
+    BIT-identical to LGEN_GEMM_STEADY=0, and both are held to the oracle's bf16 linear."""
+    from llamagen_amd.engine import pack_act, pack_weight, unpack_act
+    L, dev = _L(), _dev()
+    dt, code = torch.bfloat16, _code(torch.bfloat16)
+    x, w = _rand((M, K), dt, 13, 0.5), _rand((N, K), dt, 14, 0.02)
+    mts = (M + 15) // 16
+    mts = (mts + 7) // 8 * 8 if mts > 4 else mts
+    mt, nt, kw = tiles
+    xp, wp = pack_act(x.to(dev), mts), pack_weight(w.to(dev))
+    h0 = _rand((M, N), dt, 15)
+    w13 = torch.stack([wp[: N // 32], wp[N // 32:]], dim=1).flatten(0, 1).contiguous()   # w1 = first half of the rows, w3 = second
+
+    def run():
+        rows = torch.zeros(mts * 16, N, dtype=dt, device=dev)
+        L.check(L.lib().lgen_gemm(L.ptr(wp), L.ptr(xp), L.ptr(rows), M, mts, N, K, L.EPI_ROWS, code, mt, nt, kw, 0, 0, 0, 0.0, 0, L.stream()), "rows")
+        hp = pack_act(h0.to(dev), mts)
+        ssq = torch.zeros(mts * 16 * 256, dtype=torch.float32, device=dev)
+        L.check(L.lib().lgen_gemm(L.ptr(wp), L.ptr(xp), L.ptr(hp), M, mts, N, K, L.EPI_RES, code, mt, nt, kw, 0, 0, 0, 0.0, L.ptr(ssq), L.stream()), "res")
+        out = [rows, hp, ssq]
+        if nt % 2 == 0:
+            g = torch.zeros(N // 2 // 32, mts, 64, 8, dtype=dt, device=dev)
+            L.check(L.lib().lgen_gemm(L.ptr(w13), L.ptr(xp), L.ptr(g), M, mts, N, K, L.EPI_SWIGLU, code, mt, nt, kw, 0, 0, 0, 0.0, 0, L.stream()), "swiglu")
+            out.append(g)
+        torch.cuda.synchronize()
+        return out
+
+    monkeypatch.setenv("LGEN_GEMM_STEADY", "0")
+    generic = run()
+    monkeypatch.delenv("LGEN_GEMM_STEADY")
+    steady = run()
+    for a, b, what in zip(generic, steady, ("rows", "residual", "statistics", "swiglu")):
+        assert torch.equal(a, b), what
+    ref = O.linear(x.float(), w.float(), dt)
+    _close(steady[0][:M], ref, dt, "steady rows")
+    _close(unpack_act(steady[1], M), O._rnd(h0.float() + ref, dt), dt, "steady res", mag=ref)
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("M,d,F,tiles", [(64, 1024, 2816, (4, 1, 8)), (5, 256, 512, (1, 1, 2)), (33, 800, 2304, (4, 1, 5)),
                                         (128, 1024, 512, (8, 1, 4))])

@@ -262,12 +262,17 @@ class DecodeEngine:
         if self.lean and self.MTs >= 16 and self.fuse_norm and bf16 and kind in ("w13", "wo", "w2"):
             return {"w13": (2, 2, 8), "wo": (2, 2, 4) if (ntiles >= 96 and kch // 4 >= 12) else (2, 1, 8),
                     "w2": (2, 2, 4 if kch // 4 >= 12 else 8)}[kind]
-        if self.MTs >= 16 and bf16 and not self.fuse_norm and kch >= 96:
+        if self.MTs >= 8 and bf16 and not self.fuse_norm and kch >= 96:
             # wide models (GPT-3B: d 3200, F 8704) at 256 rows: every GEMM is the plain ring kernel and the work is MFMA-shaped
             # (64 GFLOP per layer), so big tiles and FEW K-splitting waves win -- measured (tools/gemm_sweep_wide.py,
             # profiles/r03_wide_sweep.log): qkv (4, 4, 4) 45.0 us against (4, 2, 8) 54.7, wo (4, 4, 4) 18.2 / 26.9, w1||w3 (8, 2, 4)
             # 64.4 / 84.1, w2 (4, 4, 8) 40.1 / 66.6, lm_head (8, 2, 4) 47.5 / 68.4: 4.07 ms of GEMMs per decode step instead of 5.64
-            mt, nt = {"qkv": (4, 4), "wo": (4, 4), "w13": (8, 2), "w2": (4, 4), "head": (8, 2)}[kind]
+            # at 128 rows: qkv (4, 4, 4) 29.5 us against (4, 2, 8) 34.5, wo (4, 2, 4) 12.9 / 16.3, w1||w3 (4, 4, 4) 43.4 / 51.0,
+            # w2 (4, 2, 8) 28.8 / 37.1, lm_head (8, 2, 4) 26.3 / 36.9: 2.78 ms per step instead of 3.37
+            if self.MTs >= 16:
+                mt, nt = {"qkv": (4, 4), "wo": (4, 4), "w13": (8, 2), "w2": (4, 4), "head": (8, 2)}[kind]
+            else:
+                mt, nt = {"qkv": (4, 4), "wo": (4, 2), "w13": (4, 4), "w2": (4, 2), "head": (8, 2)}[kind]
             while ntiles % nt:
                 nt //= 2
             while self.MTs % mt:

@@ -67,11 +67,13 @@ def sweep(m, rows, out):
     }
     scheds = [(1, 0), (2, 0), (2, 1), (3, 0), (3, 1), (4, 1), (6, 1), (8, 1)]
     cands = {
-        "qkv": [(1, 4, 8), (2, 4, 8), (2, 2, 8), (4, 2, 8), (4, 4, 8)],
-        "w13": [(1, 4, 8), (2, 4, 8), (2, 2, 8), (4, 2, 8), (4, 4, 8)],
-        "head": [(1, 4, 8), (2, 4, 8), (4, 2, 8), (4, 4, 8)],
-        "wo": [(1, 1, 8), (2, 1, 8), (4, 1, 8), (2, 2, 8), (2, 1, 4)],
-        "w2": [(1, 1, 16), (2, 1, 16), (2, 1, 8), (4, 1, 8), (2, 2, 8), (1, 2, 16)],
+        # kw = 4 shapes of the fused GEMMs fall through to the ring kernel's RMSNorm prologue (the register-resident form needs
+        # 8 waves x 3..6 chunks): the wide-model sweep (profiles/r03_wide_sweep.log) says big tiles x 4 waves are worth a look
+        "qkv": [(1, 4, 8), (2, 4, 8), (2, 2, 8), (4, 2, 8), (4, 4, 8), (4, 2, 4), (2, 4, 4)],
+        "w13": [(1, 4, 8), (2, 4, 8), (2, 2, 8), (4, 2, 8), (4, 4, 8), (4, 4, 4), (4, 2, 4), (2, 4, 4)],
+        "head": [(1, 4, 8), (2, 4, 8), (4, 2, 8), (4, 4, 8), (4, 4, 4), (4, 2, 4)],
+        "wo": [(1, 1, 8), (2, 1, 8), (4, 1, 8), (2, 2, 8), (2, 1, 4), (2, 2, 4), (4, 2, 4)],
+        "w2": [(1, 1, 16), (2, 1, 16), (2, 1, 8), (4, 1, 8), (2, 2, 8), (1, 2, 16), (2, 2, 4), (4, 1, 4), (4, 2, 4)],
     }
     best = {}
     for kind, (fn, launches, nbytes) in kinds.items():

@@ -141,6 +141,29 @@ def test_tile_heuristics_are_valid_for_every_registry_model(lib):
     assert not bad, bad[:10]
 
 
+def test_measured_tile_tables_of_round_3(lib):
+    """The shapes the round-3 sweeps measured best (profiles/r03_wide_sweep.log) are the ones engine._tiles hands out: wide models
+    (GPT-3B: not fused, >= 96 k-chunks) at 128 / 256 rows, and the 4-wave RES GEMMs of the fused-norm models at 256 rows."""
+    import types
+    from llamagen_amd.engine import DecodeEngine
+
+    def tiles(d, F, mts, fuse, lean=False):
+        eng = types.SimpleNamespace(tile_override={}, pass_override={}, fuse_norm=fuse, mt=min(mts, 4), MTs=mts, kc=32, lib=lib,
+                                    lean=lean, dtype=torch.bfloat16)
+        return {k: DecodeEngine._tiles(eng, k, n, kk) for k, n, kk in (("qkv", 3 * d, d), ("wo", d, d), ("w13", 2 * F, d),
+                                                                      ("w2", d, F), ("head", 16384, d))}
+    assert tiles(3200, 8704, 16, False) == {"qkv": (4, 4, 4), "wo": (4, 4, 4), "w13": (8, 2, 4), "w2": (4, 4, 8), "head": (8, 2, 4)}
+    assert tiles(3200, 8704, 8, False) == {"qkv": (4, 4, 4), "wo": (4, 2, 4), "w13": (4, 4, 4), "w2": (4, 2, 8), "head": (8, 2, 4)}
+    small = tiles(3200, 8704, 4, False)                                   # 64 rows: the generic rule, untouched
+    assert small["w13"][0] <= 4 and small["qkv"][2] == 8
+    gl = tiles(1024, 2816, 16, True)                                      # GPT-L, 256 rows
+    assert gl["w2"] == (2, 2, 4) and gl["wo"] == (4, 1, 8) and gl["qkv"] == (1, 4, 8) and gl["w13"] == (2, 4, 8)
+    assert tiles(1024, 2816, 16, True, lean=True)["w2"] == (2, 2, 4) and tiles(1024, 2816, 16, True, lean=True)["wo"] == (2, 1, 8)
+    gx = tiles(1536, 4096, 16, True)                                      # GPT-XXL: wo has 96 n-tiles and 12 chunks per wave at kw 4
+    assert gx["wo"] == (2, 2, 4) and gx["w2"] == (2, 2, 4) and tiles(1536, 4096, 16, True, lean=True)["wo"] == (2, 2, 4)
+    assert tiles(1024, 2816, 8, True)["w2"] != (2, 2, 4)                  # 128 rows keep the round-2 shapes
+
+
 def test_hot_kernels_have_no_register_spills():
     """The build leaves the compiler's per-kernel resource report next to every object
     (llamagen_amd/csrc/*.usage, -Rpass-analysis=kernel-resource-usage).  Every kernel of the library must be free

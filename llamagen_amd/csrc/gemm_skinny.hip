@@ -198,6 +198,10 @@ __global__ __launch_bounds__((gemm_max_threads<MT, NT, NORM, EPI>())) void gemm_
     }
 }
 
+// ring-buffer shapes whose operand set does not fit 256 VGPRs (they would spill; csrc/gemm_skinny.usage): refused, not compiled
+template <int MT, int NT, int EPI, bool NORM>
+constexpr bool gemm_spills() { return NORM && (MT == 8 || (MT == 4 && NT == 4 && EPI == EPI_QKV)); }
+
 // ---- steady-state form for wide models (round 3) ---------------------------------------------------------------------
 // Same operation, same wave partition and the same chunk order per wave as gemm_kernel<..., NORM = false> -- bit-identical
 // results -- for K ranges that are long and uniform: every wave owns KCH / KW chunks (exact) and at least 2 * DEPTH of them
@@ -209,8 +213,12 @@ __global__ __launch_bounds__((gemm_max_threads<MT, NT, NORM, EPI>())) void gemm_
 // 200-340 TFLOP/s on GPT-3B's GEMMs).  Here the epilogue's operands are requested FIRST (older requests do not disturb the
 // count), the ring fill is unconditional, the loop is do-while, and a sched_barrier after each stage keeps the stage order, so
 // the waits become vmcnt((DEPTH - 1) * loads per stage): DEPTH - 1 stages stay in flight under the MFMAs of the oldest.
-template <typename D, int MT, int NT, int EPI, int DEPTH>
-__global__ __launch_bounds__((gemm_max_threads<MT, NT, false, EPI>())) void gemm_steady_kernel(GemmArgs a) {
+// NORM: the RMSNorm prologue of gemm_kernel<..., NORM = true> (row scales from the producer's partial sums of squares, applied to
+// the B operand chunk by chunk); the statistics are read and reduced BEFORE the ring is filled, so they are older requests too.
+// Reachable through explicit tile shapes only (LGEN_TILES with kw < 8 on a fused-norm model: the register-resident form needs
+// 8 waves x 3..6 chunks) -- an experiment hook for round 4, see DESIGN section 9 item 0.
+template <typename D, int MT, int NT, int EPI, int DEPTH, bool NORM = false>
+__global__ __launch_bounds__((gemm_max_threads<MT, NT, NORM, EPI>())) void gemm_steady_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) float4 red[];
     constexpr int TILES = NT * MT;
     constexpr int UNITS = EPI == EPI_SWIGLU ? (TILES / 2 > 0 ? TILES / 2 : 1) : TILES;
@@ -244,16 +252,32 @@ __global__ __launch_bounds__((gemm_max_threads<MT, NT, false, EPI>())) void gemm
             }
         }
     }
-    uint4 A[DEPTH][NT], B[DEPTH][MT];
+    float ri[MT];
+    if constexpr (NORM) {  // fixed-order statistics, as in gemm_kernel
+        float ssum[MT];
+        ssq_rows_now<MT>(a.ssq_in, a.parts, mt0, lane, ssum);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            float s = ssum[i];
+            s += __shfl_xor(s, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            ri[i] = 1.0f / sqrtf(s * a.inv_k + a.eps);
+        }
+    }
+    uint4 A[DEPTH][NT], B[DEPTH][MT], WN[DEPTH];
 #define LGEN_LOAD(s, kk)                                                                                  \
     {                                                                                                     \
         _Pragma("unroll") for (int j = 0; j < NT; ++j) A[s][j] = ldg_w(wbase + j * wstride + (size_t)(kk) * 64); \
         _Pragma("unroll") for (int i = 0; i < MT; ++i) B[s][i] = xbase[(size_t)(kk) * xstride + i * 64];  \
+        if constexpr (NORM) WN[s] = a.nw[(size_t)(kk) * 4 + (lane >> 4)];                                \
     }
 #define LGEN_MMA(s)                                                                                       \
     {                                                                                                     \
-        _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                    \
-            _Pragma("unroll") for (int j = 0; j < NT; ++j) acc[j][i] = D::mma(A[s][j], B[s][i], acc[j][i]); \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                                  \
+            uint4 b_ = B[s][i];                                                                           \
+            if constexpr (NORM) b_ = D::norm_chunk(b_, ri[i], WN[s]);                                     \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j) acc[j][i] = D::mma(A[s][j], b_, acc[j][i]);    \
+        }                                                                                                 \
     }
 #pragma unroll
     for (int s = 0; s < DEPTH; ++s) LGEN_LOAD(s, k0 + s);
@@ -337,19 +361,24 @@ __global__ __launch_bounds__((gemm_max_threads<MT, NT, false, EPI>())) void gemm
 // tile shapes with a steady-state instantiation: the ones the host heuristics can pick for wide models at 128 / 256 rows
 template <typename D, int MT, int NT, int EPI, bool NORM>
 constexpr bool gemm_has_steady() {
-    return std::is_same<D, BF16>::value && !NORM && (EPI == EPI_RES || EPI == EPI_SWIGLU || EPI == EPI_QKV || EPI == EPI_ROWS) &&
+    if (!std::is_same<D, BF16>::value) return false;
+    if (NORM)  // experiment hook (explicit tile shapes only): shapes that fit the register file with the prologue's extras
+        return (EPI == EPI_SWIGLU || EPI == EPI_QKV || EPI == EPI_ROWS) && !gemm_spills<MT, NT, EPI, NORM>() &&
+               ((MT == 4 && (NT == 2 || NT == 4)) || (MT == 2 && NT == 4));
+    return (EPI == EPI_RES || EPI == EPI_SWIGLU || EPI == EPI_QKV || EPI == EPI_ROWS) &&
            ((MT == 4 && (NT == 1 || NT == 2 || NT == 4)) || (MT == 2 && (NT == 2 || NT == 4)) || (MT == 8 && (NT == 1 || NT == 2)));
 }
 
 // LGEN_GEMM_STEADY=0 keeps the generic form (the parity test compares the two; read at launch = capture time)
-static bool steady_enabled() {
+static bool steady_enabled(bool norm) {
+    if (norm) {  // the RMSNorm-prologue variant is opt-in (LGEN_GEMM_STEADY_NORM=1): compiled and ISA-checked in round 3, not yet measured
+        const char* n = getenv("LGEN_GEMM_STEADY_NORM");
+        return n && n[0] == '1';
+    }
     const char* e = getenv("LGEN_GEMM_STEADY");
     return !(e && e[0] == '0');
 }
 
-// ring-buffer shapes whose operand set does not fit 256 VGPRs (they would spill; csrc/gemm_skinny.usage): refused, not compiled
-template <int MT, int NT, int EPI, bool NORM>
-constexpr bool gemm_spills() { return NORM && (MT == 8 || (MT == 4 && NT == 4 && EPI == EPI_QKV)); }
 
 template <typename D, int MT, int NT, int EPI, bool NORM>
 static int launch(const GemmArgs& a, int kw, hipStream_t st) {
@@ -361,13 +390,13 @@ static int launch(const GemmArgs& a, int kw, hipStream_t st) {
     size_t lds = kw > 1 ? (size_t)kw * NT * MT * 64 * sizeof(float4) : 0;
     if (lds > 160 * 1024 || kw * 64 > gemm_max_threads<MT, NT, NORM, EPI>()) return LGEN_ERR_BAD_ARG;
     if constexpr (gemm_has_steady<D, MT, NT, EPI, NORM>()) {
-        if (a.KCH % kw == 0 && a.KCH / kw >= 2 * DEPTH && steady_enabled()) {
+        if (a.KCH % kw == 0 && a.KCH / kw >= 2 * DEPTH && steady_enabled(NORM)) {
             if (lds > 64 * 1024) {
-                hipError_t e = hipFuncSetAttribute((const void*)gemm_steady_kernel<D, MT, NT, EPI, DEPTH>,
+                hipError_t e = hipFuncSetAttribute((const void*)gemm_steady_kernel<D, MT, NT, EPI, DEPTH, NORM>,
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 if (e != hipSuccess) return (int)e;
             }
-            hipLaunchKernelGGL((gemm_steady_kernel<D, MT, NT, EPI, DEPTH>), grid, dim3(64 * kw), lds, st, a);
+            hipLaunchKernelGGL((gemm_steady_kernel<D, MT, NT, EPI, DEPTH, NORM>), grid, dim3(64 * kw), lds, st, a);
             LGEN_CHECK_LAUNCH();
             return 0;
         }

@@ -1,6 +1,8 @@
 """GPU parity tests of the GPT decode path: every HIP kernel against the CPU oracle on the same
 seeded inputs, then whole generate() runs against the reference-made goldens.  All calls go through
 the C ABI (ctypes) exactly like the product does."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -250,6 +252,44 @@ def test_fused_rmsnorm_chain(dt, M, d, F, tiles):
     e_ref = table[idx.long()].float()
     assert torch.equal(unpack_act(hp, M).float().cpu(), e_ref)
     np.testing.assert_allclose(ssq2[:M, :d // 16].sum(1).cpu().numpy(), (e_ref.double() ** 2).sum(-1).float().numpy(), rtol=1e-5)
+
+
+@pytest.mark.skipif(os.environ.get("LGEN_EXPERIMENTAL") != "1", reason="round-4 experiment hook (LGEN_EXPERIMENTAL=1): the RMSNorm-prologue "
+                    "variant of the steady-state ring kernel is compiled and ISA-checked but was never run on a GPU in round 3")
+@pytest.mark.parametrize("M,d,F,tiles", [(256, 1024, 2816, (4, 4, 4)), (256, 1024, 2816, (2, 4, 4)), (128, 1536, 4096, (4, 2, 4))])
+def test_gemm_steady_state_norm_prologue_is_bit_identical(M, d, F, tiles, monkeypatch):
+    """LGEN_GEMM_STEADY_NORM=1: fused-norm GEMMs with kw = 4 (the register-resident form needs 8 waves) run the steady-state ring
+    kernel with the RMSNorm prologue; same statistics, wave partition and chunk order as the generic prologue kernel -> identical bits."""
+    from llamagen_amd.engine import pack_act, pack_weight
+    L, dev = _L(), _dev()
+    lib, dt, code = L.lib(), torch.bfloat16, _code(torch.bfloat16)
+    mts = (M + 15) // 16
+    mt, nt, kw = tiles
+    h = _rand((M, d), dt, 41)
+    nw = (1 + 0.1 * _rand((d,), torch.float32, 42)).to(dt).to(dev)
+    w1, w3, wout = _rand((F, d), dt, 43, 0.05), _rand((F, d), dt, 44, 0.05), _rand((512, d), dt, 45, 0.05)
+    hp = pack_act(h.to(dev), mts)
+    ssq = torch.zeros(mts * 16, L.SSQ_STRIDE, device=dev)
+    L.check(lib.lgen_ssq_pack(L.ptr(hp), L.ptr(ssq), mts, d, code, L.stream()), "ssq_pack")
+    w13 = torch.stack([pack_weight(w1.to(dev)), pack_weight(w3.to(dev))], dim=1).flatten(0, 1).contiguous()
+    woutp = pack_weight(wout.to(dev))
+
+    def run():
+        gp = torch.zeros(F // 32, mts, 64, 8, dtype=dt, device=dev)
+        rows = torch.zeros(mts * 16, 512, dtype=dt, device=dev)
+        L.check(lib.lgen_gemm(L.ptr(w13), L.ptr(hp), L.ptr(gp), M, mts, 2 * F, d, L.EPI_SWIGLU, code, mt, nt, kw, L.ptr(nw), L.ptr(ssq),
+                              d // 16, 1e-5, 0, L.stream()), "norm+swiglu")
+        L.check(lib.lgen_gemm(L.ptr(woutp), L.ptr(hp), L.ptr(rows), M, mts, 512, d, L.EPI_ROWS, code, mt, nt, kw, L.ptr(nw), L.ptr(ssq),
+                              d // 16, 1e-5, 0, L.stream()), "norm+rows")
+        torch.cuda.synchronize()
+        return gp, rows
+
+    generic = run()
+    monkeypatch.setenv("LGEN_GEMM_STEADY_NORM", "1")
+    steady = run()
+    assert torch.equal(generic[0], steady[0]) and torch.equal(generic[1], steady[1])
+    xn = O.rms_norm(h.float(), nw.cpu(), 1e-5, dt)
+    _close(steady[1][:M], O.linear(xn, wout.float(), dt), dt, "steady norm+rows", frac_ulp1=0.05)
 
 
 @pytest.mark.parametrize("dt", DTYPES)

@@ -97,7 +97,7 @@ def measure_attention(gpt, B2, N, T=1, npos=12, reps=5):
             def chain():
                 for i in range(e.L):
                     L.check(lib.lgen_attn_decode(L.ptr(e.qbuf), L.ptr(e.k_cache[i]), L.ptr(e.v_cache[i]), L.ptr(e.ap),
-                                                 L.ptr(e.state), 0, 0, B2, e.MTs, e.H, e.hd, e.hdp, e.S8, e.kvs, e.dt, L.stream()), "attn")
+                                                 L.ptr(e.state), 0, 0, B2, e.MTs, e.H, e.hd, e.hdp, e.S8, e.kvs, e.dt, e.attn_variant, L.stream()), "attn")
             chain()
             stream.synchronize()
             g = torch.cuda.CUDAGraph()
@@ -121,33 +121,22 @@ def measure_attention(gpt, B2, N, T=1, npos=12, reps=5):
 
 
 def measure_gemms(gpt, reps=5):
-    """Second kernel family of the decode step (HBM / latency-bound skinny GEMMs): live HIP-event timing of captured
-    chains that contain ONLY one kind of GEMM, over all layers' weights in turn (nothing cache-resident), with the
-    tile shapes the decode graph uses.  Returns {kind: (us per launch, weight bytes per launch)}."""
+    """Second kernel family of the decode step (the five GEMMs of a layer + lm_head): live HIP-event timing of captured chains that
+    contain ONLY one kind of GEMM, over all layers' weights in turn (nothing cache-resident), through the engine's own launch
+    methods, i.e. with the kernel family (big-M tile / skinny), tile shapes and schedules the decode graph uses.
+    Returns {kind: (us per launch, weight bytes per launch)} + "_schedule"."""
     from llamagen_amd import _lib as L
     e = gpt._engine
-    lib, dt, M, mts = e.lib, e.dt, e.B2, e.MTs
-    d, F, H, hd, hdp, S8, V = e.d, e.F, e.H, e.hd, e.hdp, e.S8, e.V
-    tq, to, t13, t2, th = (e._tiles("qkv", 3 * d, d), e._tiles("wo", d, d), e._tiles("w13", 2 * F, d), e._tiles("w2", d, F),
-                           e._tiles("head", V, d))
+    d, F, V = e.d, e.F, e.V
     e.ssq_parts = d // 16
     e.state.zero_()
     nw = lambda w: w if e.fuse_norm else None
-    sq, s13, sh = e._passes("qkv", 3 * d, tq), e._passes("w13", 2 * F, t13), e._passes("head", V, th)   # the decode graph's schedules
-
-    def qkv():
-        for w in e.layers:
-            if e.fuse_norm and sq[0] > 1:
-                L.check(lib.lgen_gemm_schedule_hint(sq[0], sq[1]), "hint")
-            L.check(lib.lgen_gemm_qkv_rope(L.ptr(w["wqkv"]), L.ptr(e.hp), L.ptr(e.qbuf), L.ptr(e.k_cache[0]), L.ptr(e.v_cache[0]),
-                                           L.ptr(e.freqs_cis), L.ptr(e.state), M, mts, d, H, hd, hdp, S8, e.kvs, dt, tq[0], tq[1], tq[2],
-                                           L.ptr(nw(w["an"])), L.ptr(e.ssq if e.fuse_norm else None), e.ssq_parts, e.eps, L.stream()), "qkv")
     kinds = {
-        "wqkv": (qkv, 3 * d * d),
-        "wo": (lambda: [e.gemm(w["wo"], e.ap, e.hp, M, mts, d, d, L.EPI_RES, to, ssq_out=e.ssq if e.fuse_norm else None) for w in e.layers], d * d),
-        "w13": (lambda: [e.gemm(w["w13"], e.hp, e.gp, M, mts, 2 * F, d, L.EPI_SWIGLU, t13, norm_w=nw(w["fn"]), sched=s13) for w in e.layers], 2 * F * d),
-        "w2": (lambda: [e.gemm(w["w2"], e.gp, e.hp, M, mts, d, F, L.EPI_RES, t2, ssq_out=e.ssq if e.fuse_norm else None) for w in e.layers], F * d),
-        "lm_head": (lambda: [e.gemm(e.out_w, e.hp, e.logits, M, mts, V, d, L.EPI_ROWS, th, norm_w=nw(e.norm_w), sched=sh) for _ in range(4)], V * d),
+        "wqkv": (lambda: [e.qkv_gemm(0, w, e.hp, nw(w["an"])) for w in e.layers], 3 * d * d),
+        "wo": (lambda: [e.gemm_kind("wo", w) for w in e.layers], d * d),
+        "w13": (lambda: [e.gemm_kind("w13", w, e.hp, nw(w["fn"])) for w in e.layers], 2 * F * d),
+        "w2": (lambda: [e.gemm_kind("w2", w) for w in e.layers], F * d),
+        "lm_head": (lambda: [e.gemm_kind("head", None, e.hp, nw(e.norm_w)) for _ in range(4)], V * d),
     }
     esz = 2 if e.dtype == torch.bfloat16 else 4
     stream = torch.cuda.Stream()
@@ -170,8 +159,7 @@ def measure_gemms(gpt, reps=5):
                 stream.synchronize()
                 best = min(best, e0.elapsed_time(e1) * 1e3 / (reps * launches))
             out[kind] = (best, nparam * esz)
-    out["_schedule"] = {"tiles": {"wqkv": tq, "wo": to, "w13": t13, "w2": t2, "lm_head": th},
-                        "passes": {"wqkv": sq[0], "w13": s13[0], "lm_head": sh[0]}}
+    out["_schedule"] = e.gemm_schedule()
     return out
 
 
@@ -444,8 +432,8 @@ def standin_main(args, rank, local, world, rccl_ranks):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=24)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json configs[1..4]; 2 = the headline")
     ap.add_argument("--lanes", type=int, default=0, help="decode chains in flight per GPU (llamagen_amd/pipeline.py); "
                                                          "0 = pick 1..3 from the step count")
@@ -453,14 +441,13 @@ def main():
                                                                      "0 = the config's default")
     ap.add_argument("--steps-per-turn", type=int, default=1, help="decode steps a lane enqueues per scheduler turn")
     ap.add_argument("--vq-own-stream", action="store_true", help="decode images on a separate shared stream (measured slower)")
-    ap.add_argument("--lane-cu-mask", action="store_true", help="experiment: every lane's stream owns 1/lanes of the CUs")
-    ap.add_argument("--vq-cus", type=int, default=0, help="experiment: confine the VQ decoder to this many CUs (one masked stream)")
-    ap.add_argument("--lanes-avoid-vq-cus", action="store_true", help="experiment: with --vq-cus, keep the decode lanes off those CUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-live-traffic", action="store_true", help="quote the committed PMC pass instead of running rocprofv3 --pmc now")
     ap.add_argument("--no-solo", action="store_true", help="skip the extra one-generate()-at-a-time leg (keeps a "
                                                            "rocprofv3 kernel average of this run to the timed chain shape)")
+    ap.add_argument("--allow-untested-schedule", action="store_true", help="run a GEMM schedule no end-to-end parity test names")
+    ap.add_argument("--no-one-chain", action="store_true", help="skip the extra one-chain-in-flight leg (it needs another chain's KV slabs)")
     ap.add_argument("--standin", action="store_true", help=argparse.SUPPRESS)  # CPU/gloo test of the launch path, see standin_main
     args = ap.parse_args()
 
@@ -505,26 +492,42 @@ def main():
         lens = torch.randint(5, T + 1, (B,), generator=g)
         emb_masks = (torch.arange(T).unsqueeze(0) >= (T - lens).unsqueeze(1)).to(torch.int64).to(dev)
         skw["emb_masks"] = emb_masks
-    # batches per decode chain: 256 rows for the 32-image configs (2, 3), 256 for GPT-3B's 64-image batches, 128 for the 16-caption t2i batch
-    bpc = args.batches_per_chain if args.batches_per_chain > 0 else {2: DEFAULT_BPC, 3: 4, 4: 2, 5: 4}[args.config]
+    # Schedule (round 4).  Config 2: TWO decode chains in flight, each carrying half of the run's steps (batches of 32) -- up to 16,
+    # i.e. up to 1024 rows with CFG.  Measured on MI355X (gpurun_out/ab2.log, attn_ab3/4.log; img/s, tile GEMMs + persistent
+    # attention): 4 x 3 chains 107-110, 8 x 3 116, 8 x 2 119-120, 16 x 2 120, 16 x 1 107 -- per image the GEMM cost falls with the rows
+    # of a chain (weights and launch chain amortised: 6.2 / 4.4 / 3.7 us per image-step at 256 / 512 / 1024 rows), attention and the
+    # decoder do not care, and two wide chains overlap better than three narrow ones.  Every batch still is its own generate() (own
+    # labels, own Exp(1) draws in the reference's order, rows never interact before the sampler).  Other configs: as in round 3.
+    if args.batches_per_chain > 0:
+        bpc = args.batches_per_chain
+    elif args.config == 2:
+        bpc = max(1, min(12, (args.steps + 1) // 2))   # <= 768 rows: the tile shapes tests/test_gpu_headline.py holds to the oracle
+    else:
+        bpc = {3: 4, 4: 2, 5: 4}[args.config]
     chains = (args.steps + bpc - 1) // bpc
+    cfg_m = gpt.config
+    hdp = 64 if cfg_m.dim // cfg_m.n_head <= 64 else 128
+    per_chain = (cfg_m.n_layer * 2 * B * bpc * cfg_m.n_head * (T + N + 8) * hdp * 2 * 2      # K and V slabs, CFG rows
+                 + N * B * bpc * cfg_m.vocab_size * 4)                                        # Exp(1) noise
     if args.lanes <= 0:
-        # k chains in flight take ~T_k (measured, relative to one chain alone: 1, 1.44, 2.02 at 64 rows; 1, 1.5, 2.1 at 128);
-        # a run of C chains on L lanes costs floor(C/L) * T_L + T_(C mod L): use the cheapest L
-        # (round 3, 256-row chains with the decoder in 32-image pieces: 1, 1.71, 2.49 -- tools/exp_r3c.py)
-        Tk = {0: 0.0, 1: 1.0, 2: 1.44, 3: 2.02} if bpc == 1 else ({0: 0.0, 1: 1.0, 2: 1.5, 3: 2.1} if bpc < 4 else
-                                                                   {0: 0.0, 1: 1.0, 2: 1.71, 3: 2.49})
-        args.lanes = min((1, 2, 3), key=lambda l: (chains // l) * Tk[l] + Tk[chains % l])
+        if args.config == 2:
+            args.lanes = min(2, chains)
+        else:
+            # k chains in flight take ~T_k (round 3, 256-row chains with the decoder in 32-image pieces: 1, 1.71, 2.49 -- tools/exp_r3c.py);
+            # a run of C chains on L lanes costs floor(C/L) * T_L + T_(C mod L): use the cheapest L
+            Tk = {0: 0.0, 1: 1.0, 2: 1.44, 3: 2.02} if bpc == 1 else ({0: 0.0, 1: 1.0, 2: 1.5, 3: 2.1} if bpc < 4 else
+                                                                       {0: 0.0, 1: 1.0, 2: 1.71, 3: 2.49})
+            args.lanes = min((1, 2, 3), key=lambda l: (chains // l) * Tk[l] + Tk[chains % l])
         # KV slabs + noise of the chains in flight must fit the 288 GB of HBM3E with room for weights and decoder activations
-        cfg_m = gpt.config
-        hdp = 64 if cfg_m.dim // cfg_m.n_head <= 64 else 128
-        per_chain = (cfg_m.n_layer * 2 * B * bpc * cfg_m.n_head * (T + N + 8) * hdp * 2 * 2      # K and V slabs, CFG rows
-                     + N * B * bpc * cfg_m.vocab_size * 4)                                        # Exp(1) noise
-        while args.lanes > 1 and args.lanes * per_chain > 180e9:
+        while args.lanes > 1 and args.lanes * per_chain > HBM_BUDGET_BYTES:
             args.lanes -= 1
+    # per-rank HBM budget, checked BEFORE anything is allocated (the one-chain transparency leg below needs one more chain's worth)
+    need = (args.lanes + (0 if (args.no_one_chain or args.lanes == 1) else 1)) * per_chain
+    if need > HBM_BUDGET_BYTES + 60e9:
+        raise SystemExit(f"schedule needs {need / 1e9:.0f} GB of KV slabs + noise per GPU ({args.lanes} chains x {bpc} batches of {B}): "
+                         f"over the {HBM_BUDGET_BYTES / 1e9:.0f} GB budget; lower --batches-per-chain or --lanes")
     pipe = SamplingPipeline(gpt, vq, lanes=args.lanes, steps_per_turn=args.steps_per_turn, vq_low_priority=args.vq_own_stream,
-                            cu_partition=True if args.lane_cu_mask else None, vq_cus=args.vq_cus,
-                            lanes_avoid_vq_cus=args.lanes_avoid_vq_cus, batches_per_chain=bpc,
+                            batches_per_chain=bpc,
                             vq_chunk=B if (bpc > 1 and args.lanes > 1) else 0)  # decode_code() batch by batch: finer interleaving
     pipe.prepare(B, N, **skw)  # setup (like loading weights): KV slabs, workspaces, decode graphs per lane
     torch.cuda.synchronize()
@@ -565,7 +568,7 @@ def main():
     # transparency: the same workload with ONE chain in flight (2 chains, one after the other, on a lane of their own with the
     # single-chain GEMM shapes), outside the timed region above
     chain1 = None
-    if args.lanes > 1:
+    if args.lanes > 1 and not args.no_one_chain:
         view = gpt.lane_view()
         one = SamplingPipeline(view, vq, lanes=1, batches_per_chain=bpc)
         one.prepare(B, N, **skw)
@@ -625,16 +628,32 @@ def main():
                                "launch_us_by_position": per_pos}
             gm = measure_gemms(pipe.lanes[0].gpt)
             gsched = gm.pop("_schedule")
+            # the GEMM schedule the timed region replayed must be one an end-to-end oracle test names (tests/test_gpu_headline.py)
+            from llamagen_amd.engine import TESTED_TILE_SCHEDULES, TILE_SCHEDULES
+            tiles_run = {k: tuple(v_.get("shape(wm,wn,mtv,ntv,kb,stages,lw)", ())) for k, v_ in gsched.items()}
+            names = {"wqkv": "qkv", "wo": "wo", "w13": "w13", "w2": "w2", "lm_head": "head"}
+            tested = any(all(tiles_run[k] == TILE_SCHEDULES[m][names[k]] for k in tiles_run) for m in TESTED_TILE_SCHEDULES)
+            if args.config == 2 and not tested and not args.allow_untested_schedule:
+                raise SystemExit(f"GEMM schedule {gsched} is not one tests/test_gpu_headline.py holds to the oracle "
+                                 "(--allow-untested-schedule to run it anyway)")
             nlay = gpt.config.n_layer
             tot_us = sum(us * (1 if k == "lm_head" else nlay) for k, (us, _) in gm.items())
             tot_b = sum(b * (1 if k == "lm_head" else nlay) for k, (_, b) in gm.items())
-            res["roofline_gemm"] = {"bound": "hbm", "kernel": f"decode-step GEMM family (weight-streaming, M = {rows})",
+            tot_flop = 2.0 * rows * tot_b / 2          # 2 x rows x parameters (bf16: 2 bytes per parameter)
+            tflops = tot_flop / tot_us / 1e6
+            frac_hbm, frac_mfma = tot_b / tot_us / 1e3 / HBM_PEAK_GBS, tflops / MFMA_BF16_PEAK_TFLOPS
+            # intensity = rows FLOP per weight byte against the ridge 2.5 PF / 8 TB/s = 312: below it the weight stream bounds
+            res["roofline_gemm"] = {"bound": "hbm" if rows < 312 else "mfma", "kernel": f"decode-step GEMM family (M = {rows} rows)",
                                     "achieved": round(tot_b / tot_us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                    "frac": round(tot_b / tot_us / 1e3 / HBM_PEAK_GBS, 4),
+                                    "frac": round(max(frac_hbm, frac_mfma), 4), "frac_hbm": round(frac_hbm, 4),
+                                    "frac_mfma": round(frac_mfma, 4), "achieved_TFLOPs": round(tflops, 1),
+                                    "mfma_peak_TFLOPs": MFMA_BF16_PEAK_TFLOPS, "flop_per_weight_byte": rows,
                                     "weight_bytes_per_step": int(tot_b), "us_per_step": round(tot_us, 1),
                                     "us_per_step_per_128_rows": round(tot_us * 128 / rows, 1), "schedule": gsched,
+                                    "schedule_tested_end_to_end": bool(tested),
                                     "launches_per_step": pipe.lanes[0].gpt._engine.launches_per_step(),
                                     "per_launch": {k: {"us": round(us, 2), "weight_bytes": int(b), "GB/s": round(b / us / 1e3, 1),
+                                                       "TFLOPs": round(rows * b / us / 1e6, 1),
                                                        "fetch_over_algorithmic": (pmc.get("gemm", {}).get(k) or {}).get("fetch_over_algorithmic")}
                                                    for k, (us, b) in gm.items()},
                                     "traffic_source": (pmc.get("gemm") or {}).get("source")}
@@ -709,7 +728,8 @@ def main():
         dist.destroy_process_group()
 
 
-DEFAULT_BPC = 4          # c2i: consecutive batches per decode chain (256 rows at config 2)
+HBM_BUDGET_BYTES = 180e9   # KV slabs + noise of the chains in flight per GPU (288 GB HBM3E minus weights, decoder activations, slack)
+MFMA_BF16_PEAK_TFLOPS = 2500.0
 PMC_JSON = "r03_pmc.json"
 
 

@@ -5,14 +5,13 @@
  * underneath our Python host mirror (llamagen_amd/): `extern "C"`, raw device pointers + sizes,
  * a `hipStream_t` passed as void*, no torch types, no allocation, no synchronisation; every entry
  * point only enqueues kernels on the given stream (hipGraph-capture safe) and returns 0 or a
- * hipError_t / LGEN_ERR_* code.  State held inside the library, all of it process-wide and none of
- * it data: (1) the kernel-variant / cache-policy selectors of the "tuning knobs" section below
- * (lgen_set_*: plain ints read at launch time -- set them before the first launch, not concurrently
- * with launches from another thread; a captured graph keeps the variant it was captured with),
- * (2) one-shot `hipFuncSetAttribute` flags for the kernels that need more than 64 KiB of LDS (set on
- * first use for the current device; a process that drives several devices from one thread should
- * make one warm-up call per device), (3) the per-thread, one-shot lgen_prefetch_hint.  Each entry point cites the reference
- * op sequence it replaces (paths relative to the reference repository root).
+ * hipError_t / LGEN_ERR_* code.  ABI v7: every schedule / kernel-variant choice of the product path is an explicit ARGUMENT of the
+ * call it applies to (workgroup shape, `passes`, attention `variant`); the one-shot per-thread hints of v4-v6 are gone.  What is left
+ * inside the library: (1) one-shot `hipFuncSetAttribute` flags for the kernels that need more than 64 KiB of LDS (set on first use
+ * for the current device) and the cached CU count of the persistent attention form; (2) the development switches of the
+ * `lgen_debug_*` section at the end of this header (process-wide ints read at launch time, never set by the product path) and the
+ * LGEN_GEMM_STEADY / LGEN_TILE_ABLATE environment variables (read at launch = capture time; bit-identical results / timing
+ * ablations).  Each entry point cites the reference op sequence it replaces (paths relative to the reference repository root).
  *
  * Fragment-packed layouts ("chunk" = 1 KiB = [16 rows][KC k] in MFMA operand order, lane =
  * g*16 + r holds row r, k-slice g*EPL..+EPL; bf16: KC=32, EPL=8; fp32: KC=16, EPL=4):
@@ -26,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LGEN_ABI_VERSION 6
+#define LGEN_ABI_VERSION 7
 #define LGEN_BF16 0
 #define LGEN_F32 1
 #define LGEN_F16 2   /* fp16 storage: BF16's layouts (KC = 32, EPL = 8), IEEE half rounding, v_mfma_f32_16x16x32_f16 */
@@ -73,10 +72,12 @@ int lgen_rmsnorm(const void* hp, const void* weight, void* xnp, int MTs, int d, 
  *     rnd(rnd(x * rsqrt(mean(x^2) + eps)) * norm_w) to the operand on the fly; mean(x^2) comes from
  *     ssq_in[MTs*16][LGEN_SSQ_STRIDE] fp32: ssq_parts partial row sums of squares per row (summed in a fixed order);
  *   ssq_out != NULL (RES only): also writes ssq_out[row][N/16 partials], the per-(row, 16-column tile) sums of
- *     squares of the updated residual stream, i.e. the ssq_in (ssq_parts = N/16) of the next norm. */
+ *     squares of the updated residual stream, i.e. the ssq_in (ssq_parts = N/16) of the next norm.
+ *   passes (1..64): fused-norm form only (csrc/gemm_normpre.hip) -- consecutive n-groups one workgroup walks with its normalised
+ *     rows kept in registers; any value gives bit-identical results (a scheduling choice); 1 elsewhere. */
 int lgen_gemm(const void* wp, const void* xp, void* out, int M, int MTs, int N, int K, int epilogue_kind, int dtype,
               int mt, int nt, int kw, const void* norm_w, const float* ssq_in, int ssq_parts, float eps,
-              float* ssq_out, void* stream);
+              float* ssq_out, int passes, void* stream);
 
 /* Largest kw (K-splitting waves per workgroup) the (mt, nt) tile shape of that kernel variant admits. */
 int lgen_gemm_max_kw(int epilogue_kind, int fused_norm, int mt, int nt);
@@ -86,21 +87,42 @@ int lgen_gemm_max_kw(int epilogue_kind, int fused_norm, int mt, int nt);
  * q_out [MTs*16][H][hdp]; caches [B2][H][S8] rows of hdp elements, kv_row_stride elements apart (0 = hdp;
  * 2*hdp with v_cache = k_cache + hdp is the interleaved K|V slab the engine uses: one HBM stream per (b, h));
  * freqs [P][hd/2][2] fp32 from precompute_freqs_cis_2d (gpt.py:404-417); norm_w / ssq_in / ssq_parts / eps as
- * in lgen_gemm. */
+ * in lgen_gemm; passes as in lgen_gemm. */
 int lgen_gemm_qkv_rope(const void* wp, const void* xp, void* q_out, void* k_cache, void* v_cache, const float* freqs,
                        const int* pos_ptr, int M, int MTs, int d, int n_head, int hd, int hdp, int S8,
                        int kv_row_stride, int dtype, int mt, int nt, int kw, const void* norm_w, const float* ssq_in,
-                       int ssq_parts, float eps, void* stream);
+                       int ssq_parts, float eps, int passes, void* stream);
+
+/* The same two operations for wide chains (>= 128 rows), bf16 storage: the big-M tile family (csrc/gemm_tile.hip).  A workgroup of
+ * wm x wn waves owns (wm*mtv*16 rows) x (wn*ntv*16 columns) of the output over the whole K range -- waves split the tile, never K --
+ * and both operands stream through an LDS ring of `stages` slots of `kb` k-chunks (global_load_lds, counted waits; lw = 4: issued
+ * by four extra loader waves, one per SIMD, so that DMA issue overlaps the MFMA work; lw = 0: by the computing waves): every weight
+ * byte enters a CU once per (row block), no cross-wave reduction.  Same operands, epilogues, RMSNorm fusion and summation-order
+ * contract for the statistics as lgen_gemm / lgen_gemm_qkv_rope (gpt.py:161-167,199-226,238-240,253-257,367-368); the accumulation
+ * order over K differs from the skinny kernels (one wave walks all of K), so results agree with them to fp32-accumulation
+ * round-off, not bit for bit.  LGEN_ERR_UNSUPPORTED: no instantiation of that shape / shape does not divide (MTs % (wm*mtv),
+ * (K/32) % kb) / LDS budget exceeded: the caller picks another shape or the skinny kernel.  EPI_RES, and with norm_w EPI_ROWS /
+ * EPI_SWIGLU (lgen_gemm_tile) and the fused-norm qkv form (lgen_gemm_qkv_rope_tile; one position for all rows). */
+int lgen_gemm_tile(const void* wp, const void* xp, void* out, int M, int MTs, int N, int K, int epilogue_kind, int dtype,
+                   int wm, int wn, int mtv, int ntv, int kb, int stages, int lw, const void* norm_w, const float* ssq_in,
+                   int ssq_parts, float eps, float* ssq_out, void* stream);
+int lgen_gemm_qkv_rope_tile(const void* wp, const void* xp, void* q_out, void* k_cache, void* v_cache, const float* freqs,
+                            const int* pos_ptr, int M, int MTs, int d, int n_head, int hd, int hdp, int S8,
+                            int kv_row_stride, int dtype, int wm, int wn, int mtv, int ntv, int kb, int stages, int lw,
+                            const void* norm_w, const float* ssq_in, int ssq_parts, float eps, void* stream);
 
 /* Attention.forward back half (gpt.py:229-236): repeat_interleave + math-backend SDPA with
  * causal_mask[:, pos] -- here: single-query attention over the first *pos_ptr+1 cache slots.
  * mask: null = pure causal, else the reference's causal_mask [B2][S8][S8] (1 byte per entry, as
  * modified by generate.py:154-163 for t2i emb_masks); row *pos_ptr of it gates the keys < mask_len (0 = all
  * S8; generate.py only ever clears columns of the T-token prefix, so mask_len = T skips the byte loads for
- * the image tokens). */
+ * the image tokens).  variant: -1 = the library's choice by shape (one head per 128-thread workgroup below 256 rows; from 256
+ * rows the PERSISTENT form: one 4-wave workgroup per CU whose waves walk whole (row, head) items with 16 KiB of K/V loads in
+ * flight each -- 64 KB per CU instead of 160, so that the HBM queue stays short for the other chains' kernels), else 0..13
+ * (csrc/gpt_ops.hip lists them; every variant computes the same wave-level online softmax). */
 int lgen_attn_decode(const void* q, const void* k_cache, const void* v_cache, void* out_packed, const int* pos_ptr,
                      const unsigned char* mask, int mask_len, int B2, int MTs, int n_head, int hd, int hdp, int S8,
-                     int kv_row_stride, int dtype, void* stream);
+                     int kv_row_stride, int dtype, int variant, void* stream);
 
 /* ---- sequence prefill (t2i prefix: all T = cls_token_num caption positions of all B2 rows per layer at once; rows
  * r = t * B2 + b of the packed activations; generate.py:77-86 + gpt.py:348-349 with emb_masks folded into
@@ -144,12 +166,12 @@ int lgen_embed_rows(const void* tok_table, const void* cls_table, const int* cur
 int lgen_gemm_qkv_rope_rows(const void* wp, const void* xp, void* q_out, void* k_cache, void* v_cache, const float* freqs,
                             const int* row_pos, int M, int MTs, int d, int n_head, int hd, int hdp, int S8,
                             int kv_row_stride, int dtype, int mt, int nt, int kw, const void* norm_w, const float* ssq_in,
-                            int ssq_parts, float eps, void* stream);
+                            int ssq_parts, float eps, int passes, void* stream);
 
 /* lgen_attn_decode with kv_len of row b = row_pos[b] + 1. */
 int lgen_attn_decode_rows(const void* q, const void* k_cache, const void* v_cache, void* out_packed, const int* row_pos,
                           const unsigned char* mask, int mask_len, int B2, int MTs, int n_head, int hd, int hdp, int S8,
-                          int kv_row_stride, int dtype, void* stream);
+                          int kv_row_stride, int dtype, int variant, void* stream);
 
 /* lgen_sample per slot: slot b is at step row_step[b] of max_steps (>= max_steps: empty / finished, skipped); its Exp(1) draws
  * are noise[(b*max_steps + step)*V ..]; writes seq[b][step], cur_tok[b] (and cur_tok[B+b]), then advances row_step[b] and
@@ -231,32 +253,12 @@ int lgen_resize_bicubic(const float* in_nchw, float* out_nchw, int BC, int Hi, i
 /* torch.clamp(127.5 * x + 128.0, 0, 255).permute(0, 2, 3, 1).to(uint8): fp32 NCHW -> uint8 NHWC. */
 int lgen_to_uint8_hwc(const float* in_nchw, unsigned char* out_nhwc, int B, int C, int H, int W, void* stream);
 
-/* One-shot hint (per host thread): the next lgen_gemm / lgen_gemm_qkv_rope / lgen_attn_decode launch also
- * issues fire-and-forget reads of [next_weights, +bytes) -- the weight matrix of the kernel that follows it in
- * the decode chain -- so that the successor starts on a warm memory-side cache.  NULL clears it. */
-int lgen_prefetch_hint(const void* next_weights, long long bytes);
-
-/* One-shot schedule (per host thread) of the next FUSED-NORM lgen_gemm / lgen_gemm_qkv_rope[_rows] launch (ABI v6): the
- * workgroup keeps its normalised activation rows in registers and walks `passes` consecutive n-groups (mt x nt tiles each),
- * so that `attention_norm` / `ffn_norm` / `norm` (gpt.py:253-256, 367) are evaluated once per `passes` n-groups and the weight
- * stream of group g+1 overlaps the reduction / epilogue of group g; `double_buffer` != 0 keeps the next group's weights in a
- * second register set.  Like the prefetch hint it is baked into the launch's kernel arguments (graph-capture safe) and then
- * cleared; launches without a fused norm ignore it.  Results are identical for every (passes, double_buffer). */
-int lgen_gemm_schedule_hint(int passes, int double_buffer);
-
-/* ---- tuning knobs (process-wide kernel variant selection; defaults are the measured-best ones) ---- */
-int lgen_set_attn_variant(int v);  /* (K/V loads per buffer, waves per (b,h)): 2 (default) = (2,2); 1 = (2,4); 0 = (4,4); 3 = (4,2); 4 = (2,1); 5 = (4,1); 6 / 7 = (2,2) with 2 / 4 heads of a row per workgroup (n_head must be a multiple) */
-int lgen_set_vq_nt(int v);         /* VQ decoder: non-temporal fp32 activation stores / GroupNorm-pass loads (0 = off) */
-int lgen_set_prefill_mfma(int v);       /* lgen_attn_prefill, bf16: 1 (default) MFMA flash kernel; 0 the VALU kernels (always used for fp32) */
-int lgen_set_conv_fused_variant(int v); /* lgen_conv_fused weight tiles: 1 (default) global -> LDS DMA; 0 through staging registers */
-int lgen_set_igemm_variant(int v); /* 3 (default): 128x128 tile, 2 staging sets for pixels / 1 for weights; 0: 1 set; 2: 128x64 tiles; 1 (2 full sets, spilled) is refused */
-
-/* ---- lane streams (host-side plumbing for llamagen_amd/pipeline.py; no reference counterpart) ----
- * A HIP stream whose kernels may only occupy the CUs whose bit is set in mask_words (bit i of word i/32 = CU i;
- * hipExtStreamCreateWithCUMask): lets every in-flight batch own a slice of the chip, so that the latency-bound
- * decode kernels of different batches run side by side instead of taking turns.  *stream_out is a hipStream_t. */
-int lgen_stream_create_cu_mask(const unsigned int* mask_words, int n_words, void** stream_out);
-int lgen_stream_destroy(void* stream);
+/* ---- lgen_debug_*: development switches (process-wide ints, read at launch time; the product path never calls them and every
+ * default is the measured-best choice; kept for A/B measurements and for the parity tests that hold both forms to the oracle) ---- */
+int lgen_debug_set_vq_nt(int v);              /* VQ decoder: non-temporal fp32 activation stores / GroupNorm-pass loads (default 0 = off) */
+int lgen_debug_set_prefill_mfma(int v);       /* lgen_attn_prefill, bf16: 1 (default) MFMA flash kernel; 0 the VALU kernels (always used for fp32) */
+int lgen_debug_set_conv_fused_variant(int v); /* lgen_conv_fused weight tiles: 1 (default) global -> LDS DMA; 0 through staging registers */
+int lgen_debug_set_igemm_variant(int v);      /* 3 (default): 128x128 tile, 2 staging sets for pixels / 1 for weights; 0: 1 set; 2: 128x64 tiles; 1 is refused */
 
 #ifdef __cplusplus
 }

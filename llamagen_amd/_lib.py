@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblgen_hip.so")
 BF16, F32, F16 = 0, 1, 2
 EPI_ROWS, EPI_PACKED, EPI_GELU, EPI_RES, EPI_SWIGLU, EPI_QKV = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 6
+ABI_VERSION = 7
 SSQ_STRIDE = 256  # LGEN_SSQ_STRIDE: floats per row of a fused-RMSNorm statistics array
 ERR_UNSUPPORTED = -2
 
@@ -30,28 +30,25 @@ SIGNATURES = {
     "lgen_embed_pack": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "lgen_ssq_pack": [_P, _P, _I, _I, _I, _P],
     "lgen_rmsnorm": [_P, _P, _P, _I, _I, _F, _I, _P],
-    "lgen_gemm": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _F, _P, _P],
+    "lgen_gemm": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _F, _P, _I, _P],
     "lgen_gemm_max_kw": [_I, _I, _I, _I],
-    "lgen_gemm_qkv_rope": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _F, _P],
+    "lgen_gemm_qkv_rope": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _F, _I, _P],
+    "lgen_gemm_tile": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _F, _P, _P],
+    "lgen_gemm_qkv_rope_tile": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _F, _P],
     "lgen_resize_bicubic": [_P, _P, _I, _I, _I, _I, _I, _P],
     "lgen_to_uint8_hwc": [_P, _P, _I, _I, _I, _I, _P],
-    "lgen_prefetch_hint": [_P, _c.c_longlong],
-    "lgen_gemm_schedule_hint": [_I, _I],
-    "lgen_set_attn_variant": [_I],
-    "lgen_set_igemm_variant": [_I],
-    "lgen_set_prefill_mfma": [_I],
-    "lgen_set_conv_fused_variant": [_I],
-    "lgen_stream_create_cu_mask": [_P, _I, _P],
-    "lgen_stream_destroy": [_P],
-    "lgen_set_vq_nt": [_I],
-    "lgen_attn_decode": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "lgen_debug_set_igemm_variant": [_I],
+    "lgen_debug_set_prefill_mfma": [_I],
+    "lgen_debug_set_conv_fused_variant": [_I],
+    "lgen_debug_set_vq_nt": [_I],
+    "lgen_attn_decode": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "lgen_rope_append_prefill": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "lgen_attn_prefill": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "lgen_sample": [_P, _P, _c.c_longlong, _P, _P, _P, _I, _I, _I, _I, _F, _I, _F, _I, _F, _I, _I, _P],
     "lgen_advance_state": [_P, _P],
     "lgen_embed_rows": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
-    "lgen_gemm_qkv_rope_rows": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _F, _P],
-    "lgen_attn_decode_rows": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "lgen_gemm_qkv_rope_rows": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _F, _I, _P],
+    "lgen_attn_decode_rows": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "lgen_sample_rows": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _F, _I, _F, _I, _I, _P],
     "lgen_vq_codebook_prep": [_P, _P, _P, _I, _I, _I, _P],
     "lgen_vq_lookup_pqconv": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],

@@ -412,8 +412,8 @@ static int launch_cf(const ConvFArgs& a, int B, hipStream_t st) {
     return 0;
 }
 
-static int g_cf_dma = 1;  // weight tiles by LDS-DMA (1) or through staging registers (0); lgen_set_conv_fused_variant
-extern "C" int lgen_set_conv_fused_variant(int v) { g_cf_dma = v ? 1 : 0; return 0; }
+static int g_cf_dma = 1;  // weight tiles by LDS-DMA (1) or through staging registers (0); lgen_debug_set_conv_fused_variant
+extern "C" int lgen_debug_set_conv_fused_variant(int v) { g_cf_dma = v ? 1 : 0; return 0; }
 
 // weight tile width (output channels per workgroup) this library uses for a given Cout: the host packs to it
 extern "C" int lgen_conv_fused_bn(int Cout) { return Cout >= 128 ? 128 : (Cout > 16 ? 64 : 16); }

@@ -283,7 +283,7 @@ int lgen_vq_nt();  // vq_ops.hip
 // tuning knob (tools/): 0 = 128x128 tile, one staging set; 1 = 128x128, two staging sets; 2 = 128x64 tiles, two sets;
 // 3 = 128x128, two sets for the pixel tile only
 static int g_igemm_variant = 3;
-extern "C" int lgen_set_igemm_variant(int v) {
+extern "C" int lgen_debug_set_igemm_variant(int v) {
     if (v == 1) return LGEN_ERR_UNSUPPORTED;  // double-staged both operands: 144 B of scratch per lane, removed in round 3
     g_igemm_variant = v;
     return 0;

@@ -23,41 +23,14 @@ struct GemmArgs {
     int kvs;             // QKV: elements between consecutive cache rows (hdp, or 2*hdp for an interleaved K|V slab)
     int parts;
     float eps, inv_k;
-    const char* pf;      // weights of the NEXT kernel of the chain (nullable): pulled towards the memory-side cache
-    long long pf_bytes;
     int passes;          // fused-norm GEMMs: consecutive n-groups one workgroup walks with its activations kept in registers (>= 1)
-    int db;              // fused-norm GEMMs: weights of the next n-group in a second register set (1) or reloaded after the MFMAs (0)
+    int db;              // gemm_tile.hip: development ablation mask (LGEN_TILE_ABLATE), 0 in production
 };
 // weight chunk load: default cache policy (chains in flight share the weights through the memory-side cache; measured better than
 // non-temporal).  One plain load, NOT a run-time choice of policy: a branch per load makes the compiler lose count of the loads in
 // flight and wait for all of them (s_waitcnt vmcnt(0)) in front of the first MFMA, which turns the operand ring into load-all /
 // wait-all / compute-all (round 2, found in the ISA of gemm_kernel<BF16,2,1,EPI_RES,false,6>).
 LGEN_DEV uint4 ldg_w(const uint4* p) { return *p; }
-
-// Fire-and-forget reads of the next kernel's weight matrix, one dword per 64-byte line, issued BEFORE this
-// wave's own operand loads.  Each kernel of the decode chain is latency-bound and starts with a cold weight
-// stream (~1 us of its ~5 us); the chain's successor finds its weights in the memory-side cache instead.
-// Only 4 bytes per line travel to the CU, and loads retire in order, so by the time the wave's own operands
-// (requested later) have arrived these have too: nothing ever waits specifically for them.  Inline asm
-// because hipcc must neither eliminate the loads nor reuse their destination register early: the returned
-// token has to be passed to prefetch_retire() AFTER the wave has consumed its own loads.
-LGEN_DEV unsigned prefetch_lines(const char* base, long long bytes, int part, int nparts, int lane) {
-    unsigned junk = 0;
-    if (!base) return junk;
-    const long long per = ((bytes / nparts + 4095) / 4096) * 4096;  // bytes per participating wave
-    const long long lo = (long long)part * per;
-    for (long long off = lo + lane * 64; off < lo + per && off < bytes; off += 4096) {
-        const char* p = base + off;
-        asm volatile("global_load_dword %0, %1, off" : "+v"(junk) : "v"(p));
-    }
-    return junk;
-}
-// vmcnt(0): free when the wave has consumed its own (younger) loads; required for waves that had none.
-// Only when a prefetch was actually issued (uniform branch): an unconditional wait would make idle attention
-// waves sit out their speculative first K/V loads.
-LGEN_DEV void prefetch_retire(const char* base, unsigned token) {
-    if (base) asm volatile("s_waitcnt vmcnt(0)" ::"v"(token) : "memory");
-}
 
 // This lane's share of one row's sum of squares: lane group q4 = lane >> 4 sums a contiguous quarter of the row's `parts`
 // partials; the caller adds the four groups (xor 16, 32).  Fast path (parts a multiple of 16, <= 128: every registry model):
@@ -243,20 +216,114 @@ LGEN_DEV void epilogue(const GemmArgs& a, int nt, int mt, int lane, f32x4_t v, f
             float y2 = x2 * fz - x3 * fw, y3 = x3 * fz + x2 * fw;
             x0 = y0; x1 = y1; x2 = y2; x3 = y3;
         }
-        if (sec == 0) {
-            D::st4(a.out, ((size_t)m * a.H + head) * a.hdp + dd, x0, x1, x2, x3);
-        } else {
-            void* cache = sec == 1 ? a.kc : a.vc;
-            D::st4(cache, (((size_t)m * a.H + head) * a.S8 + pos) * a.kvs + dd, x0, x1, x2, x3);
-        }
+        // (pointers and strides read into values FIRST: selecting between the ADDRESSES of kernel-argument fields made the compiler
+        // spill them to 40 B of scratch once `a` arrived through a helper's reference)
+        void* const po = a.out;
+        void* const pk = a.kc;
+        void* const pv = a.vc;
+        const int hdp = a.hdp, kvs = a.kvs;
+        const size_t rh = (size_t)m * a.H + head;
+        void* const dst = sec == 0 ? po : (sec == 1 ? pk : pv);
+        const size_t off = sec == 0 ? rh * hdp + dd : (rh * a.S8 + pos) * kvs + dd;
+        D::st4(dst, off, x0, x1, x2, x3);
     }
 }
 
 template <int EPI> constexpr bool epi_has_aux() { return EPI == EPI_RES || EPI == EPI_QKV; }
 
 
+// ---- what every K-splitting GEMM kernel does around its MFMA loop (gemm_kernel, gemm_steady_kernel, np_pass) ----------------
+// Epilogue work items ("units") of a workgroup tile: one per 16x16 output tile, one per (w1, w3) tile pair for SwiGLU.  With
+// KW > 1 waves unit u belongs to wave u % KW (its q-th unit is u = w + q * KW); with one wave all units are its own.
+template <int MT>
+struct RowPos { int v[MT]; };   // by value: an `int (&)[MT]` parameter kept the array in scratch for (MT, NT, EPI) = (2, 1, QKV)
+template <int MT>
+LGEN_DEV int pick_pos(const RowPos<MT>& p, int i) {
+    int r = 0;
+#pragma unroll
+    for (int k = 0; k < MT; ++k) r |= p.v[k] & -(int)(i == k);
+    return r;
+}
+
+template <int MT, int NT, int EPI>
+constexpr int gemm_units() { return EPI == EPI_SWIGLU ? (NT * MT / 2 > 0 ? NT * MT / 2 : 1) : NT * MT; }
+
+// memory operands of this wave's units, requested before the main loop
+template <typename D, int MT, int NT, int EPI>
+LGEN_DEV void gemm_aux_prefetch(const GemmArgs& a, uint4 (&aux)[gemm_units<MT, NT, EPI>()], int w, int KW, int lane, int nt0, int mt0,
+                                const int (&posr_)[MT]) {
+    RowPos<MT> posr;
+#pragma unroll
+    for (int k = 0; k < MT; ++k) posr.v[k] = posr_[k];
+    constexpr int UNITS = gemm_units<MT, NT, EPI>();
+#pragma unroll
+    for (int q = 0; q < UNITS; ++q) aux[q] = make_uint4(0, 0, 0, 0);
+    if constexpr (epi_has_aux<EPI>()) {
+#pragma unroll
+        for (int q = 0; q < UNITS; ++q) {
+            const int u = w + q * KW;   // (q >= ceil(UNITS / 2) never matches when KW >= 2)
+            if (u < UNITS) {
+                const int j = u / MT, i = u - j * MT;
+                aux[q] = epi_prefetch<D, EPI>(a, nt0 + j, mt0 + i, lane, pick_pos<MT>(posr, i));
+            }
+        }
+    }
+}
+
+// cross-wave K reduction through LDS in a FIXED order (wave 0, 1, 2, ...: deterministic, no atomics) + the fused epilogue of this
+// wave's units.  `red` = this pass's reduction buffer ([KW][NT * MT][64] float4); KW == 1: no LDS, no barrier.
+template <typename D, int MT, int NT, int EPI>
+LGEN_DEV void gemm_reduce_epilogue(const GemmArgs& a, const f32x4_t (&acc)[NT][MT], float4* red, int w, int KW, int lane, int nt0,
+                                   int mt0, const int (&posr_)[MT], const uint4 (&aux)[gemm_units<MT, NT, EPI>()]) {
+    constexpr int TILES = NT * MT, UNITS = gemm_units<MT, NT, EPI>(), UPW = (UNITS + 1) / 2;
+    RowPos<MT> posr;
+#pragma unroll
+    for (int k = 0; k < MT; ++k) posr.v[k] = posr_[k];
+    if (KW == 1) {
+#pragma unroll
+        for (int q = 0; q < UNITS; ++q) {
+            if constexpr (EPI == EPI_SWIGLU) {
+                const int jp = q / MT, i = q - jp * MT;
+                epilogue<D, EPI>(a, nt0 + 2 * jp, mt0 + i, lane, acc[2 * jp][i], acc[(2 * jp + 1) % NT][i], aux[q], pick_pos<MT>(posr, i));
+            } else {
+                const int j = q / MT, i = q - j * MT;
+                epilogue<D, EPI>(a, nt0 + j, mt0 + i, lane, acc[j][i], acc[j][i], aux[q], pick_pos<MT>(posr, i));
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const f32x4_t v = acc[j][i];
+            red[((size_t)w * TILES + j * MT + i) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    __syncthreads();
+    auto rsum = [&](int t) {
+        float4 s = red[(size_t)t * 64 + lane];
+        for (int ww = 1; ww < KW; ++ww) {
+            const float4 p = red[((size_t)ww * TILES + t) * 64 + lane];
+            s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+        }
+        return f32x4_t{s.x, s.y, s.z, s.w};
+    };
+#pragma unroll
+    for (int q = 0; q < UPW; ++q) {
+        const int u = w + q * KW;
+        if (u < UNITS) {
+            if constexpr (EPI == EPI_SWIGLU) {
+                const int jp = u / MT, i = u - jp * MT;
+                epilogue<D, EPI>(a, nt0 + 2 * jp, mt0 + i, lane, rsum((2 * jp) * MT + i), rsum((2 * jp + 1) * MT + i), aux[q], pick_pos<MT>(posr, i));
+            } else {
+                const int j = u / MT, i = u - j * MT;
+                const f32x4_t v = rsum(u);
+                epilogue<D, EPI>(a, nt0 + j, mt0 + i, lane, v, v, aux[q], pick_pos<MT>(posr, i));
+            }
+        }
+    }
+}
+
 // gemm_normpre.hip: RMSNorm-fused GEMM that normalises while its weights are in flight (small K per wave);
 // returns LGEN_ERR_UNSUPPORTED when the shape is outside its envelope (caller falls back).
 int lgen_gemm_normpre_try(const GemmArgs& a, int epi, int dtype, int mt, int nt, int kw, hipStream_t st);
-void lgen_take_prefetch_hint(const char** p, long long* n);  // gemm_skinny.hip
-void lgen_take_schedule_hint(int* passes, int* db);            // gemm_skinny.hip

@@ -17,8 +17,8 @@
 // Round 3: the kernel is PERSISTENT ALONG N ("x-stationary").  A workgroup keeps its normalised activation fragments in
 // registers and walks `passes` consecutive n-groups (NT 16-row tiles of N each): the activation / statistics loads, the RMSNorm
 // VALU work and the workgroup's start-up latency are paid once per workgroup instead of once per n-group, and the weight loads
-// of n-group g+1 are in flight while n-group g is reduced through LDS and stored (DB: one whole n-group ahead, in a second
-// register set, so that they also cover the MFMAs).  Measured motivation (profiles/r03_sq_pmc.csv): waves of the one-pass form
+// of n-group g+1 are in flight while n-group g is reduced through LDS and stored.  (A second weight register set requested one
+// whole n-group ahead was measured no faster and bimodal in round 3 and removed in round 4.)  Measured motivation (profiles/r03_sq_pmc.csv): waves of the one-pass form
 // spend 58-63 % of their cycles parked on s_waitcnt / barriers with one workgroup per CU, i.e. the load phase and the compute
 // phase of a CU never overlap.  passes == 1 is the round-2 kernel.
 //
@@ -33,26 +33,12 @@ LGEN_DEV void np_load_w(uint4 (&A)[CPW][NT], const uint4* wbase, size_t wstride)
 }
 
 // MFMAs of one n-group, `between()` (the caller's next weight request), cross-wave K reduction through LDS in a fixed order
-// (wave 0, 1, 2, ...) and the fused epilogue.  `red` is this pass's reduction buffer.
+// (wave 0, 1, 2, ...) and the fused epilogue (gemm_epilogue.h).  `red` is this pass's reduction buffer.
 template <typename D, int MT, int NT, int EPI, int CPW, typename F>
 LGEN_DEV void np_pass(const GemmArgs& a, const uint4 (&A)[CPW][NT], const uint4 (&B)[CPW][MT], float4* red, int w, int KW, int lane,
                       int nt0, int mt0, const int (&posr)[MT], F&& between) {
-    constexpr int TILES = NT * MT;
-    constexpr int UNITS = EPI == EPI_SWIGLU ? (TILES / 2 > 0 ? TILES / 2 : 1) : TILES;
-    constexpr int UPW = (UNITS + 1) / 2;
-    uint4 aux[UNITS];
-#pragma unroll
-    for (int q = 0; q < UNITS; ++q) aux[q] = make_uint4(0, 0, 0, 0);
-    if constexpr (epi_has_aux<EPI>()) {
-#pragma unroll
-        for (int q = 0; q < UNITS; ++q) {
-            const int u = w + q * KW;
-            if (u < UNITS) {
-                const int j = u / MT, i = u - j * MT;
-                aux[q] = epi_prefetch<D, EPI>(a, nt0 + j, mt0 + i, lane, pick_pos<MT>(posr, i));
-            }
-        }
-    }
+    uint4 aux[gemm_units<MT, NT, EPI>()];
+    gemm_aux_prefetch<D, MT, NT, EPI>(a, aux, w, KW, lane, nt0, mt0, posr);
     f32x4_t acc[NT][MT];
 #pragma unroll
     for (int j = 0; j < NT; ++j)
@@ -65,57 +51,14 @@ LGEN_DEV void np_pass(const GemmArgs& a, const uint4 (&A)[CPW][NT], const uint4 
 #pragma unroll
             for (int j = 0; j < NT; ++j) acc[j][i] = D::mma(A[c][j], B[c][i], acc[j][i]);
     between();
-    if (KW == 1) {
-#pragma unroll
-        for (int q = 0; q < UNITS; ++q) {
-            if constexpr (EPI == EPI_SWIGLU) {
-                const int jp = q / MT, i = q - jp * MT;
-                epilogue<D, EPI>(a, nt0 + 2 * jp, mt0 + i, lane, acc[2 * jp][i], acc[(2 * jp + 1) % NT][i], aux[q], pick_pos<MT>(posr, i));
-            } else {
-                const int j = q / MT, i = q - j * MT;
-                epilogue<D, EPI>(a, nt0 + j, mt0 + i, lane, acc[j][i], acc[j][i], aux[q], pick_pos<MT>(posr, i));
-            }
-        }
-        return;
-    }
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            f32x4_t v = acc[j][i];
-            red[((size_t)w * TILES + j * MT + i) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
-        }
-    __syncthreads();
-    auto rsum = [&](int t) {
-        float4 s = red[(size_t)t * 64 + lane];
-        for (int ww = 1; ww < KW; ++ww) {
-            float4 p = red[((size_t)ww * TILES + t) * 64 + lane];
-            s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
-        }
-        return f32x4_t{s.x, s.y, s.z, s.w};
-    };
-#pragma unroll
-    for (int q = 0; q < UPW; ++q) {
-        const int u = w + q * KW;
-        if (u < UNITS) {
-            if constexpr (EPI == EPI_SWIGLU) {
-                const int jp = u / MT, i = u - jp * MT;
-                epilogue<D, EPI>(a, nt0 + 2 * jp, mt0 + i, lane, rsum((2 * jp) * MT + i), rsum((2 * jp + 1) * MT + i), aux[q], pick_pos<MT>(posr, i));
-            } else {
-                const int j = u / MT, i = u - j * MT;
-                const f32x4_t v = rsum(u);
-                epilogue<D, EPI>(a, nt0 + j, mt0 + i, lane, v, v, aux[q], pick_pos<MT>(posr, i));
-            }
-        }
-    }
+    gemm_reduce_epilogue<D, MT, NT, EPI>(a, acc, red, w, KW, lane, nt0, mt0, posr, aux);
 }
 
 // reduction buffers: two (ping-pong, one barrier per pass) when both fit the 160 KiB of LDS with 8 K-splitting waves
 template <int MT, int NT>
 constexpr bool np_red2() { return 2 * 8 * NT * MT <= 160; }
 
-// MODE 0: one n-group per workgroup (the round-2 kernel); 1: `passes` n-groups, weights reloaded after each group's MFMAs;
-// 2: `passes` n-groups, the next group's weights in a second register set
+// MODE 0: one n-group per workgroup (the round-2 kernel); 1: `passes` n-groups, weights reloaded after each group's MFMAs
 template <typename D, int MT, int NT, int EPI, int CPW, int MODE>
 __global__ __launch_bounds__(512) void gemm_normpre_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) float4 red[];
@@ -139,7 +82,6 @@ __global__ __launch_bounds__(512) void gemm_normpre_kernel(GemmArgs a) {
     int posr[MT];
     load_row_pos<MT, EPI>(a, mt0, lane, posr);
 
-    const unsigned pf_token = prefetch_lines(a.pf, a.pf_bytes, bid * KW + w, gridDim.x * KW, lane);
     // 1. activations, norm weights, row statistics
     uint4 B[CPW][MT], WN[CPW];
     const uint4* xbase = a.xp + (size_t)mt0 * 64 + lane;
@@ -175,43 +117,14 @@ __global__ __launch_bounds__(512) void gemm_normpre_kernel(GemmArgs a) {
     const size_t rstride = RED2 ? (size_t)KW * TILES * 64 : 0;
     if constexpr (MODE == 0) {
         np_pass<D, MT, NT, EPI, CPW>(a, A0, B, red, w, KW, lane, g0 * NT, mt0, posr, []() {});
-    } else if constexpr (MODE == 1) {
+    } else {
         for (int p = 0; p < np; ++p) {
             np_pass<D, MT, NT, EPI, CPW>(a, A0, B, red + (p & 1) * rstride, w, KW, lane, (g0 + p) * NT, mt0, posr, [&]() {
                 if (p + 1 < np) np_load_w<MT, NT, CPW>(A0, wbase + (size_t)(p + 1) * gstride, wstride);  // registers just consumed
             });
             if (!RED2 && p + 1 < np) __syncthreads();  // next pass rewrites `red`
         }
-    } else {
-        // weights one whole n-group ahead in a second register set; every load below is unconditional inside its block, so
-        // the compiler keeps counted waits (a load under `if` makes the join wait for vmcnt(0))
-        // (sched_barrier: without it the scheduler sinks these loads into the MFMA block below, reusing the registers the
-        // MFMAs free one by one -- which is MODE 1 again: the next group's weights would only be requested while this group
-        // computes, and every pass would start by waiting out a full memory latency)
-        uint4 A1[CPW][NT];
-        int p = 0;
-        while (p + 2 < np) {
-            np_load_w<MT, NT, CPW>(A1, wbase + (size_t)(p + 1) * gstride, wstride);
-            __builtin_amdgcn_sched_barrier(0);
-            np_pass<D, MT, NT, EPI, CPW>(a, A0, B, red, w, KW, lane, (g0 + p) * NT, mt0, posr, []() {});
-            if (!RED2) __syncthreads();
-            np_load_w<MT, NT, CPW>(A0, wbase + (size_t)(p + 2) * gstride, wstride);
-            __builtin_amdgcn_sched_barrier(0);
-            np_pass<D, MT, NT, EPI, CPW>(a, A1, B, red + rstride, w, KW, lane, (g0 + p + 1) * NT, mt0, posr, []() {});
-            if (!RED2) __syncthreads();
-            p += 2;
-        }
-        if (np - p == 2) {
-            np_load_w<MT, NT, CPW>(A1, wbase + (size_t)(p + 1) * gstride, wstride);
-            __builtin_amdgcn_sched_barrier(0);
-            np_pass<D, MT, NT, EPI, CPW>(a, A0, B, red, w, KW, lane, (g0 + p) * NT, mt0, posr, []() {});
-            if (!RED2) __syncthreads();
-            np_pass<D, MT, NT, EPI, CPW>(a, A1, B, red + rstride, w, KW, lane, (g0 + p + 1) * NT, mt0, posr, []() {});
-        } else {
-            np_pass<D, MT, NT, EPI, CPW>(a, A0, B, red, w, KW, lane, (g0 + p) * NT, mt0, posr, []() {});
-        }
     }
-    prefetch_retire(a.pf, pf_token);
 }
 
 // shapes whose operand set does not fit 256 VGPRs or that leave objects in scratch (found by compiling everything once and
@@ -221,7 +134,6 @@ constexpr bool np_spills() {
     if (MODE > 0) {
         if (!((MT == 1 && NT == 4) || (MT == 2 && NT == 2) || (MT == 2 && NT == 4) || (MT == 4 && NT == 2))) return true;
         if (MT == 4 && (EPI == EPI_QKV || CPW >= 5)) return true;
-        if (MODE == 2 && CPW * NT * 8 + CPW * MT * 4 + NT * MT * 4 > (EPI == EPI_QKV ? 180 : 200)) return true;  // + a second weight set
         if (MT == 2 && NT == 4 && EPI == EPI_QKV && CPW >= 5) return true;
         return false;
     }
@@ -255,11 +167,7 @@ static int launch_np2(const GemmArgs& a, int kw, hipStream_t st) {
 
 template <int MT, int NT, int EPI, int CPW>
 static int launch_np(const GemmArgs& a, int kw, hipStream_t st) {
-    if (a.passes > 1) {  // falls back mode by mode: double-buffered -> reload-after-MFMA -> one pass per workgroup
-        if (a.db) {
-            const int rc = launch_np2<MT, NT, EPI, CPW, 2>(a, kw, st);
-            if (rc != LGEN_ERR_UNSUPPORTED) return rc;
-        }
+    if (a.passes > 1) {  // shapes without a multi-pass instantiation fall back to one n-group per workgroup
         const int rc = launch_np2<MT, NT, EPI, CPW, 1>(a, kw, st);
         if (rc != LGEN_ERR_UNSUPPORTED) return rc;
     }

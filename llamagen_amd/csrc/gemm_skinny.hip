@@ -51,9 +51,6 @@ constexpr int gemm_max_threads() {
 template <typename D, int MT, int NT, int EPI, bool NORM, int DEPTH>
 __global__ __launch_bounds__((gemm_max_threads<MT, NT, NORM, EPI>())) void gemm_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) float4 red[];
-    constexpr int TILES = NT * MT;
-    constexpr int UNITS = EPI == EPI_SWIGLU ? (TILES / 2 > 0 ? TILES / 2 : 1) : TILES;   // epilogue work items
-    constexpr int UPW = (UNITS + 1) / 2;                           // max units per wave when KW >= 2
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int KW = blockDim.x >> 6;
@@ -68,8 +65,6 @@ __global__ __launch_bounds__((gemm_max_threads<MT, NT, NORM, EPI>())) void gemm_
     const size_t wstride = (size_t)a.KCH * 64;
     const size_t xstride = (size_t)a.MTs * 64;
 
-    const unsigned pf_token = prefetch_lines(a.pf, a.pf_bytes, (blockIdx.y * gridDim.x + blockIdx.x) * KW + w,
-                                             gridDim.x * gridDim.y * KW, lane);
     uint4 A[DEPTH][NT], B[DEPTH][MT], WN[DEPTH];
 #define LGEN_LOAD(s, kk)                                                                                  \
     {                                                                                                     \
@@ -82,21 +77,9 @@ __global__ __launch_bounds__((gemm_max_threads<MT, NT, NORM, EPI>())) void gemm_
     for (int s = 0; s < DEPTH; ++s)
         if (k0 + s < k1) LGEN_LOAD(s, k0 + s);
 
-    // 2. request what the epilogue will need (this wave's units: u = w, w + KW, ...; KW == 1: all)
-    //    (q >= UPW never matches when KW >= 2, so aux[q] lines up with the epilogue loops below)
-    uint4 aux[UNITS];
-#pragma unroll
-    for (int q = 0; q < UNITS; ++q) aux[q] = make_uint4(0, 0, 0, 0);
-    if constexpr (epi_has_aux<EPI>()) {
-#pragma unroll
-        for (int q = 0; q < UNITS; ++q) {
-            const int u = w + q * KW;
-            if (u < UNITS) {
-                const int j = u / MT, i = u - j * MT;
-                aux[q] = epi_prefetch<D, EPI>(a, nt0 + j, mt0 + i, lane, pick_pos<MT>(posr, i));
-            }
-        }
-    }
+    // 2. request what the epilogue will need (this wave's units)
+    uint4 aux[gemm_units<MT, NT, EPI>()];
+    gemm_aux_prefetch<D, MT, NT, EPI>(a, aux, w, KW, lane, nt0, mt0, posr);
 
     // 3. RMSNorm row scales from the producer's partial sums of squares (fixed order)
     float ri[MT];
@@ -150,52 +133,8 @@ __global__ __launch_bounds__((gemm_max_threads<MT, NT, NORM, EPI>())) void gemm_
 #undef LGEN_LOAD
 #undef LGEN_MMA
 
-    prefetch_retire(a.pf, pf_token);
-
-    if (KW == 1) {
-#pragma unroll
-        for (int q = 0; q < UNITS; ++q) {
-            if constexpr (EPI == EPI_SWIGLU) {
-                const int jp = q / MT, i = q - jp * MT;
-                epilogue<D, EPI>(a, nt0 + 2 * jp, mt0 + i, lane, acc[2 * jp][i], acc[(2 * jp + 1) % NT][i], aux[q], pick_pos<MT>(posr, i));
-            } else {
-                const int j = q / MT, i = q - j * MT;
-                epilogue<D, EPI>(a, nt0 + j, mt0 + i, lane, acc[j][i], acc[j][i], aux[q], pick_pos<MT>(posr, i));
-            }
-        }
-        return;
-    }
-    // cross-wave K reduction through LDS, fixed summation order (wave 0, 1, 2, ...)
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            f32x4_t v = acc[j][i];
-            red[((size_t)w * TILES + j * MT + i) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
-        }
-    __syncthreads();
-    auto rsum = [&](int t) {
-        float4 s = red[(size_t)t * 64 + lane];
-        for (int ww = 1; ww < KW; ++ww) {
-            float4 p = red[((size_t)ww * TILES + t) * 64 + lane];
-            s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
-        }
-        return f32x4_t{s.x, s.y, s.z, s.w};
-    };
-#pragma unroll
-    for (int q = 0; q < UPW; ++q) {
-        const int u = w + q * KW;
-        if (u < UNITS) {
-            if constexpr (EPI == EPI_SWIGLU) {
-                const int jp = u / MT, i = u - jp * MT;
-                epilogue<D, EPI>(a, nt0 + 2 * jp, mt0 + i, lane, rsum((2 * jp) * MT + i), rsum((2 * jp + 1) * MT + i), aux[q], pick_pos<MT>(posr, i));
-            } else {
-                const int j = u / MT, i = u - j * MT;
-                const f32x4_t v = rsum(u);
-                epilogue<D, EPI>(a, nt0 + j, mt0 + i, lane, v, v, aux[q], pick_pos<MT>(posr, i));
-            }
-        }
-    }
+    // 5. cross-wave K reduction + fused epilogue (gemm_epilogue.h)
+    gemm_reduce_epilogue<D, MT, NT, EPI>(a, acc, red, w, KW, lane, nt0, mt0, posr, aux);
 }
 
 // ring-buffer shapes whose operand set does not fit 256 VGPRs (they would spill; csrc/gemm_skinny.usage): refused, not compiled
@@ -213,16 +152,9 @@ constexpr bool gemm_spills() { return NORM && (MT == 8 || (MT == 4 && NT == 4 &&
 // 200-340 TFLOP/s on GPT-3B's GEMMs).  Here the epilogue's operands are requested FIRST (older requests do not disturb the
 // count), the ring fill is unconditional, the loop is do-while, and a sched_barrier after each stage keeps the stage order, so
 // the waits become vmcnt((DEPTH - 1) * loads per stage): DEPTH - 1 stages stay in flight under the MFMAs of the oldest.
-// NORM: the RMSNorm prologue of gemm_kernel<..., NORM = true> (row scales from the producer's partial sums of squares, applied to
-// the B operand chunk by chunk); the statistics are read and reduced BEFORE the ring is filled, so they are older requests too.
-// Reachable through explicit tile shapes only (LGEN_TILES with kw < 8 on a fused-norm model: the register-resident form needs
-// 8 waves x 3..6 chunks) -- an experiment hook for round 4, see DESIGN section 9 item 0.
-template <typename D, int MT, int NT, int EPI, int DEPTH, bool NORM = false>
-__global__ __launch_bounds__((gemm_max_threads<MT, NT, NORM, EPI>())) void gemm_steady_kernel(GemmArgs a) {
+template <typename D, int MT, int NT, int EPI, int DEPTH>
+__global__ __launch_bounds__((gemm_max_threads<MT, NT, false, EPI>())) void gemm_steady_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) float4 red[];
-    constexpr int TILES = NT * MT;
-    constexpr int UNITS = EPI == EPI_SWIGLU ? (TILES / 2 > 0 ? TILES / 2 : 1) : TILES;
-    constexpr int UPW = (UNITS + 1) / 2;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int KW = blockDim.x >> 6;
@@ -239,45 +171,18 @@ __global__ __launch_bounds__((gemm_max_threads<MT, NT, NORM, EPI>())) void gemm_
     const size_t xstride = (size_t)a.MTs * 64;
 
     // the epilogue's operands first
-    uint4 aux[UNITS];
-#pragma unroll
-    for (int q = 0; q < UNITS; ++q) aux[q] = make_uint4(0, 0, 0, 0);
-    if constexpr (epi_has_aux<EPI>()) {
-#pragma unroll
-        for (int q = 0; q < UNITS; ++q) {
-            const int u = w + q * KW;
-            if (u < UNITS) {
-                const int j = u / MT, i = u - j * MT;
-                aux[q] = epi_prefetch<D, EPI>(a, nt0 + j, mt0 + i, lane, pick_pos<MT>(posr, i));
-            }
-        }
-    }
-    float ri[MT];
-    if constexpr (NORM) {  // fixed-order statistics, as in gemm_kernel
-        float ssum[MT];
-        ssq_rows_now<MT>(a.ssq_in, a.parts, mt0, lane, ssum);
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            float s = ssum[i];
-            s += __shfl_xor(s, 16, 64);
-            s += __shfl_xor(s, 32, 64);
-            ri[i] = 1.0f / sqrtf(s * a.inv_k + a.eps);
-        }
-    }
-    uint4 A[DEPTH][NT], B[DEPTH][MT], WN[DEPTH];
+    uint4 aux[gemm_units<MT, NT, EPI>()];
+    gemm_aux_prefetch<D, MT, NT, EPI>(a, aux, w, KW, lane, nt0, mt0, posr);
+    uint4 A[DEPTH][NT], B[DEPTH][MT];
 #define LGEN_LOAD(s, kk)                                                                                  \
     {                                                                                                     \
         _Pragma("unroll") for (int j = 0; j < NT; ++j) A[s][j] = ldg_w(wbase + j * wstride + (size_t)(kk) * 64); \
         _Pragma("unroll") for (int i = 0; i < MT; ++i) B[s][i] = xbase[(size_t)(kk) * xstride + i * 64];  \
-        if constexpr (NORM) WN[s] = a.nw[(size_t)(kk) * 4 + (lane >> 4)];                                \
     }
 #define LGEN_MMA(s)                                                                                       \
     {                                                                                                     \
-        _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                                  \
-            uint4 b_ = B[s][i];                                                                           \
-            if constexpr (NORM) b_ = D::norm_chunk(b_, ri[i], WN[s]);                                     \
-            _Pragma("unroll") for (int j = 0; j < NT; ++j) acc[j][i] = D::mma(A[s][j], b_, acc[j][i]);    \
-        }                                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                    \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j) acc[j][i] = D::mma(A[s][j], B[s][i], acc[j][i]); \
     }
 #pragma unroll
     for (int s = 0; s < DEPTH; ++s) LGEN_LOAD(s, k0 + s);
@@ -312,69 +217,19 @@ __global__ __launch_bounds__((gemm_max_threads<MT, NT, NORM, EPI>())) void gemm_
 #undef LGEN_LOAD
 #undef LGEN_MMA
 
-    if (KW == 1) {
-#pragma unroll
-        for (int q = 0; q < UNITS; ++q) {
-            if constexpr (EPI == EPI_SWIGLU) {
-                const int jp = q / MT, i = q - jp * MT;
-                epilogue<D, EPI>(a, nt0 + 2 * jp, mt0 + i, lane, acc[2 * jp][i], acc[(2 * jp + 1) % NT][i], aux[q], pick_pos<MT>(posr, i));
-            } else {
-                const int j = q / MT, i = q - j * MT;
-                epilogue<D, EPI>(a, nt0 + j, mt0 + i, lane, acc[j][i], acc[j][i], aux[q], pick_pos<MT>(posr, i));
-            }
-        }
-        return;
-    }
-    // cross-wave K reduction through LDS, fixed summation order (wave 0, 1, 2, ...), as in gemm_kernel
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            f32x4_t v = acc[j][i];
-            red[((size_t)w * TILES + j * MT + i) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
-        }
-    __syncthreads();
-    auto rsum = [&](int t) {
-        float4 s = red[(size_t)t * 64 + lane];
-        for (int ww = 1; ww < KW; ++ww) {
-            float4 p = red[((size_t)ww * TILES + t) * 64 + lane];
-            s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
-        }
-        return f32x4_t{s.x, s.y, s.z, s.w};
-    };
-#pragma unroll
-    for (int q = 0; q < UPW; ++q) {
-        const int u = w + q * KW;
-        if (u < UNITS) {
-            if constexpr (EPI == EPI_SWIGLU) {
-                const int jp = u / MT, i = u - jp * MT;
-                epilogue<D, EPI>(a, nt0 + 2 * jp, mt0 + i, lane, rsum((2 * jp) * MT + i), rsum((2 * jp + 1) * MT + i), aux[q], pick_pos<MT>(posr, i));
-            } else {
-                const int j = u / MT, i = u - j * MT;
-                const f32x4_t v = rsum(u);
-                epilogue<D, EPI>(a, nt0 + j, mt0 + i, lane, v, v, aux[q], pick_pos<MT>(posr, i));
-            }
-        }
-    }
+    gemm_reduce_epilogue<D, MT, NT, EPI>(a, acc, red, w, KW, lane, nt0, mt0, posr, aux);
 }
 
 // tile shapes with a steady-state instantiation: the ones the host heuristics can pick for wide models at 128 / 256 rows
 template <typename D, int MT, int NT, int EPI, bool NORM>
 constexpr bool gemm_has_steady() {
-    if (!std::is_same<D, BF16>::value) return false;
-    if (NORM)  // experiment hook (explicit tile shapes only): shapes that fit the register file with the prologue's extras
-        return (EPI == EPI_SWIGLU || EPI == EPI_QKV || EPI == EPI_ROWS) && !gemm_spills<MT, NT, EPI, NORM>() &&
-               ((MT == 4 && (NT == 2 || NT == 4)) || (MT == 2 && NT == 4));
+    if (!std::is_same<D, BF16>::value || NORM) return false;
     return (EPI == EPI_RES || EPI == EPI_SWIGLU || EPI == EPI_QKV || EPI == EPI_ROWS) &&
            ((MT == 4 && (NT == 1 || NT == 2 || NT == 4)) || (MT == 2 && (NT == 2 || NT == 4)) || (MT == 8 && (NT == 1 || NT == 2)));
 }
 
 // LGEN_GEMM_STEADY=0 keeps the generic form (the parity test compares the two; read at launch = capture time)
-static bool steady_enabled(bool norm) {
-    if (norm) {  // the RMSNorm-prologue variant is opt-in (LGEN_GEMM_STEADY_NORM=1): compiled and ISA-checked in round 3, not yet measured
-        const char* n = getenv("LGEN_GEMM_STEADY_NORM");
-        return n && n[0] == '1';
-    }
+static bool steady_enabled() {
     const char* e = getenv("LGEN_GEMM_STEADY");
     return !(e && e[0] == '0');
 }
@@ -390,13 +245,13 @@ static int launch(const GemmArgs& a, int kw, hipStream_t st) {
     size_t lds = kw > 1 ? (size_t)kw * NT * MT * 64 * sizeof(float4) : 0;
     if (lds > 160 * 1024 || kw * 64 > gemm_max_threads<MT, NT, NORM, EPI>()) return LGEN_ERR_BAD_ARG;
     if constexpr (gemm_has_steady<D, MT, NT, EPI, NORM>()) {
-        if (a.KCH % kw == 0 && a.KCH / kw >= 2 * DEPTH && steady_enabled(NORM)) {
+        if (a.KCH % kw == 0 && a.KCH / kw >= 2 * DEPTH && steady_enabled()) {
             if (lds > 64 * 1024) {
-                hipError_t e = hipFuncSetAttribute((const void*)gemm_steady_kernel<D, MT, NT, EPI, DEPTH, NORM>,
+                hipError_t e = hipFuncSetAttribute((const void*)gemm_steady_kernel<D, MT, NT, EPI, DEPTH>,
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 if (e != hipSuccess) return (int)e;
             }
-            hipLaunchKernelGGL((gemm_steady_kernel<D, MT, NT, EPI, DEPTH, NORM>), grid, dim3(64 * kw), lds, st, a);
+            hipLaunchKernelGGL((gemm_steady_kernel<D, MT, NT, EPI, DEPTH>), grid, dim3(64 * kw), lds, st, a);
             LGEN_CHECK_LAUNCH();
             return 0;
         }
@@ -461,34 +316,6 @@ static int dispatch_norm(const GemmArgs& a, int dtype, int mt, int nt, int kw, h
     return dispatch_dt<EPI, false>(a, dtype, mt, nt, kw, st);
 }
 
-// One-shot host-side hint consumed by the next lgen_gemm / lgen_gemm_qkv_rope / lgen_attn_decode launch of
-// this thread (it is baked into that launch's kernel arguments, so a captured graph keeps it).
-thread_local const char* g_pf_ptr = nullptr;
-thread_local long long g_pf_bytes = 0;
-extern "C" int lgen_prefetch_hint(const void* next_weights, long long bytes) {
-    g_pf_ptr = (const char*)next_weights;
-    g_pf_bytes = next_weights ? bytes : 0;
-    return 0;
-}
-void lgen_take_prefetch_hint(const char** p, long long* n) {
-    *p = g_pf_ptr; *n = g_pf_bytes;
-    g_pf_ptr = nullptr; g_pf_bytes = 0;
-}
-
-// One-shot host-side schedule of the next fused-norm lgen_gemm / lgen_gemm_qkv_rope launch of this thread (baked into that
-// launch's kernel arguments like the prefetch hint): n-groups per workgroup and weight double-buffering (gemm_normpre.hip).
-thread_local int g_sched_passes = 1, g_sched_db = 0;
-extern "C" int lgen_gemm_schedule_hint(int passes, int double_buffer) {
-    if (passes < 1 || passes > 64) return LGEN_ERR_BAD_ARG;
-    g_sched_passes = passes;
-    g_sched_db = double_buffer ? 1 : 0;
-    return 0;
-}
-void lgen_take_schedule_hint(int* passes, int* db) {
-    *passes = g_sched_passes; *db = g_sched_db;
-    g_sched_passes = 1; g_sched_db = 0;
-}
-
 extern "C" int lgen_gemm_max_kw(int epilogue_kind, int fused_norm, int mt, int nt) {
     switch (epilogue_kind) {
         case LGEN_EPI_ROWS: return fused_norm ? max_kw_of<EPI_ROWS, true>(mt, nt) : max_kw_of<EPI_ROWS, false>(mt, nt);
@@ -503,17 +330,16 @@ extern "C" int lgen_gemm_max_kw(int epilogue_kind, int fused_norm, int mt, int n
 
 extern "C" int lgen_gemm(const void* wp, const void* xp, void* out, int M, int MTs, int N, int K, int epilogue_kind,
                          int dtype, int mt, int nt, int kw, const void* norm_w, const float* ssq_in, int ssq_parts,
-                         float eps, float* ssq_out, void* stream) {
+                         float eps, float* ssq_out, int passes, void* stream) {
     const int kcsz = dtype != LGEN_F32 ? 32 : 16;
-    if (N % 16 || K % kcsz || M > MTs * 16) return LGEN_ERR_BAD_ARG;
+    if (N % 16 || K % kcsz || M > MTs * 16 || passes < 1 || passes > 64) return LGEN_ERR_BAD_ARG;
     if ((norm_w && (ssq_parts < 1 || ssq_parts > LGEN_SSQ_STRIDE)) || (ssq_out && N / 16 > LGEN_SSQ_STRIDE)) return LGEN_ERR_BAD_ARG;
     GemmArgs a{};
     a.wp = (const uint4*)wp; a.xp = (const uint4*)xp; a.out = out;
     a.N = N; a.KCH = K / kcsz; a.MTs = MTs; a.M = M;
     a.nw = (const uint4*)norm_w; a.ssq_in = ssq_in; a.parts = ssq_parts; a.eps = eps; a.inv_k = 1.0f / (float)K;
     a.ssq_out = ssq_out;
-    lgen_take_prefetch_hint(&a.pf, &a.pf_bytes);
-    lgen_take_schedule_hint(&a.passes, &a.db);
+    a.passes = passes;
     hipStream_t st = (hipStream_t)stream;
     if (ssq_out && epilogue_kind != LGEN_EPI_RES) return LGEN_ERR_BAD_ARG;
     switch (epilogue_kind) {
@@ -529,9 +355,10 @@ extern "C" int lgen_gemm(const void* wp, const void* xp, void* out, int M, int M
 static int qkv_rope_impl(const void* wp, const void* xp, void* q_out, void* k_cache, void* v_cache, const float* freqs,
                          const int* pos_ptr, int pos_stride, int M, int MTs, int d, int n_head, int hd, int hdp, int S8,
                          int kv_row_stride, int dtype, int mt, int nt, int kw, const void* norm_w, const float* ssq_in,
-                         int ssq_parts, float eps, void* stream) {
+                         int ssq_parts, float eps, int passes, void* stream) {
     const int kcsz = dtype != LGEN_F32 ? 32 : 16;
-    if (d % kcsz || (3 * d) % 16 || hd % 4 || d != n_head * hd || M > MTs * 16 || pos_stride < 0 || pos_stride > 1)
+    if (d % kcsz || (3 * d) % 16 || hd % 4 || d != n_head * hd || M > MTs * 16 || pos_stride < 0 || pos_stride > 1 || passes < 1 ||
+        passes > 64)
         return LGEN_ERR_BAD_ARG;
     if (norm_w && (ssq_parts < 1 || ssq_parts > LGEN_SSQ_STRIDE)) return LGEN_ERR_BAD_ARG;
     GemmArgs a{};
@@ -542,23 +369,22 @@ static int qkv_rope_impl(const void* wp, const void* xp, void* q_out, void* k_ca
     a.kvs = kv_row_stride > 0 ? kv_row_stride : hdp;
     if (a.kvs < hdp) return LGEN_ERR_BAD_ARG;
     a.nw = (const uint4*)norm_w; a.ssq_in = ssq_in; a.parts = ssq_parts; a.eps = eps; a.inv_k = 1.0f / (float)d;
-    lgen_take_prefetch_hint(&a.pf, &a.pf_bytes);
-    lgen_take_schedule_hint(&a.passes, &a.db);
+    a.passes = passes;
     return dispatch_norm<EPI_QKV>(a, dtype, mt, nt, kw, (hipStream_t)stream);
 }
 
 extern "C" int lgen_gemm_qkv_rope(const void* wp, const void* xp, void* q_out, void* k_cache, void* v_cache,
                                   const float* freqs, const int* pos_ptr, int M, int MTs, int d, int n_head, int hd,
                                   int hdp, int S8, int kv_row_stride, int dtype, int mt, int nt, int kw,
-                                  const void* norm_w, const float* ssq_in, int ssq_parts, float eps, void* stream) {
+                                  const void* norm_w, const float* ssq_in, int ssq_parts, float eps, int passes, void* stream) {
     return qkv_rope_impl(wp, xp, q_out, k_cache, v_cache, freqs, pos_ptr, 0, M, MTs, d, n_head, hd, hdp, S8, kv_row_stride, dtype,
-                         mt, nt, kw, norm_w, ssq_in, ssq_parts, eps, stream);
+                         mt, nt, kw, norm_w, ssq_in, ssq_parts, eps, passes, stream);
 }
 
 extern "C" int lgen_gemm_qkv_rope_rows(const void* wp, const void* xp, void* q_out, void* k_cache, void* v_cache,
                                        const float* freqs, const int* row_pos, int M, int MTs, int d, int n_head, int hd,
                                        int hdp, int S8, int kv_row_stride, int dtype, int mt, int nt, int kw,
-                                       const void* norm_w, const float* ssq_in, int ssq_parts, float eps, void* stream) {
+                                       const void* norm_w, const float* ssq_in, int ssq_parts, float eps, int passes, void* stream) {
     return qkv_rope_impl(wp, xp, q_out, k_cache, v_cache, freqs, row_pos, 1, M, MTs, d, n_head, hd, hdp, S8, kv_row_stride, dtype,
-                         mt, nt, kw, norm_w, ssq_in, ssq_parts, eps, stream);
+                         mt, nt, kw, norm_w, ssq_in, ssq_parts, eps, passes, stream);
 }

@@ -1,0 +1,491 @@
+// Big-M GEMM family of the decode step (round 4): out[M, N] = x[M, K] . W[N, K]^T for chains of 128 .. 512 rows.
+//
+// Same operation, operand layouts and fused epilogues as gemm_skinny.hip / gemm_normpre.hip (the five nn.Linear of a
+// reference layer, autoregressive/models/gpt.py:161-167,199-200,238-240,367-368, with RMSNorm gpt.py:143-148, RoPE + KV append
+// gpt.py:214-226, SwiGLU gpt.py:167 and the residual adds gpt.py:255-256 fused around them), but shaped for the rows a wide
+// chain carries.  The skinny kernels split K over the 8 waves of a workgroup and own 16-32 rows: at 256 rows every weight byte
+// is pulled through L2 by 8 m-groups, every (n-group, m-group) unit pays a cross-wave LDS reduction, and the load phase of a CU
+// never overlaps its compute phase (profiles/r03_pmc.json: fetch 1.4-3.3 x algorithmic; r03_sq_pmc.csv: waves parked 58-78 %).
+//
+// Here a workgroup owns a (WM*MTV*16 rows) x (WN*NTV*16 columns) output tile over the WHOLE K range:
+//   * waves split the TILE (WM x WN), never K: no cross-wave reduction, accumulators stay in registers until the epilogue;
+//   * both operands stream HBM/L2 -> LDS through `global_load_lds_dwordx4` (the fragment-packed global layout IS the LDS
+//     image: one 1 KiB chunk per wave-instruction, lane-linear, conflict-free for the `ds_read_b128` operand reads) into a
+//     ring of STAGES slots of KB k-chunks each, with counted `s_waitcnt vmcnt` and ONE raw `s_barrier` per stage, so that
+//     STAGES-1 stages of loads stay in flight under the MFMAs of the oldest; every operand byte enters a CU once;
+//   * NORM: the RMSNorm of the rows is applied to the B fragments on their way from LDS to the MFMA (rnd(rnd(x * rinv) * w), the
+//     reference's two roundings); with WN == 1 every fragment is normalised by exactly one wave of the workgroup.  Row statistics
+//     (the producer's partial sums of squares) and the norm weight arrive through the same DMA path, summed in the fixed order of
+//     the skinny kernels (bit-identical scales);
+//   * block id -> (n-group, m-group) so that the m-groups reading the same weights sit on one XCD (one L2 fill).
+//
+// Per-CU traffic is the tile perimeter: (rows + cols) x K x 2 B.  GPT-L at 256 rows: wqkv 64 x 48 tiles -> 224 KB per CU
+// against 448 KB for the (2, 4, 8) x 3-pass skinny form.
+#include <cstdlib>
+#include <type_traits>
+
+#include "gemm_epilogue.h"
+
+typedef __attribute__((address_space(1))) const void* gt_gptr_t;
+typedef __attribute__((address_space(3))) void* gt_lptr_t;
+
+template <int N>
+LGEN_DEV void gt_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int N>
+LGEN_DEV void gt_wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+
+// LDS reads of the DMA-filled ring as inline asm.  hipcc (ROCm 7.2) cannot tell which ring slot a `ds_read` touches, so behind
+// every `global_load_lds` it puts `s_waitcnt vmcnt(0)` in front of the next LDS read it can see -- which drains the whole ring at
+// every stage (found in the ISA of the first version of this kernel).  Reads it cannot see are ordered by hand instead: DMA
+// pieces by the counted vmcnt + barrier of the stage loop, the reads themselves by a counted lgkmcnt (LDS operations return in
+// order) followed by gt_touch() on every destination, which ties the registers' uses behind the wait.
+template <int OFF>
+LGEN_DEV u32x4_t gt_lds_rd(unsigned addr) {
+    u32x4_t v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+LGEN_DEV void gt_touch(u32x4_t& v) { asm volatile("" : "+v"(v)); }
+LGEN_DEV uint4 gt_u4(const u32x4_t& v) { return make_uint4(v[0], v[1], v[2], v[3]); }
+
+template <int I, int N, typename F>
+LGEN_DEV void gt_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        gt_static_for<I + 1, N>(f);
+    }
+}
+
+// running (section, head, dd) of a q|k|v output column n, advanced 16 columns at a time (one division per wave, not per tile)
+struct QkvCol {
+    int sec, head, dd;
+    LGEN_DEV void init(int n, int d, int hd) {
+        sec = n / d;
+        const int c = n - sec * d;
+        head = c / hd;
+        dd = c - head * hd;
+    }
+    LGEN_DEV void next16(int hd, int H) {
+        dd += 16;
+        if (dd >= hd) { dd -= hd; ++head; }
+        if (head >= H) { head -= H; ++sec; }
+    }
+};
+
+// LW = 0: every wave issues its share of the DMA pieces AND computes (round-4 first form: the ~90 cycles a wave spends per
+// 1 KiB piece while four waves issue sit in front of its own MFMAs).  LW = 4: wave specialisation -- WM*WN consumer waves (LDS
+// reads, RMSNorm, MFMA, epilogue) + LW loader waves (DMA issue and the counted waits only); a workgroup's waves are dealt to
+// the SIMDs round-robin, so every SIMD holds one consumer and one loader and the DMA issue overlaps the MFMA / VALU work.
+template <typename D, int WM, int WN, int MTV, int NTV, int KB, int STAGES, int EPI, bool NORM, int LW>
+__global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_tile_kernel(GemmArgs a) {
+    constexpr int NC = WM * WN, NL = LW ? LW : NC, MTW = WM * MTV, NTW = WN * NTV;
+    constexpr int CPK = MTW + NTW;      // 1 KiB chunks per k-chunk of the workgroup tile
+    constexpr int CPS = KB * CPK;       // chunks per ring stage
+    static_assert(CPS % NL == 0, "every DMA-issuing wave issues the same number of pieces per stage");
+    constexpr int P = CPS / NL;         // DMA pieces per issuing wave per stage
+    constexpr int STAGE_B = CPS * 1024;
+    static_assert((STAGES - 1) * P <= 60, "vmcnt is a 6-bit counter");
+    static_assert(EPI != EPI_SWIGLU || (NTV % 2 == 0), "w1 / w3 tiles come in pairs");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool consumer = LW == 0 || w < NC, loader = LW == 0 || w >= NC;
+    const int lw = LW ? w - NC : w;     // index among the DMA-issuing waves
+    const int cw = w < NC ? w : 0;      // index among the consumers
+    const int wm = cw / WN, wn = cw - wm * WN;
+    const int ntiles = a.N >> 4;
+    const int gx = (ntiles + NTW - 1) / NTW, gy = a.MTs / MTW;
+    const int bid = blockIdx.x, slot0 = bid >> 3;
+    const int by = slot0 % gy, bx = (slot0 / gy) * 8 + (bid & 7);
+    if (bx >= gx) return;  // padding of the decoded grid (whole workgroup, before any barrier)
+    const int nt0 = bx * NTW, mt0 = by * MTW;
+    const int NI = a.KCH / KB;          // ring stages over K (launcher: KCH % KB == 0, NI >= STAGES - 1)
+    const int mtw0 = mt0 + wm * MTV, ntw0 = nt0 + wn * NTV;   // this wave's first m-tile / n-tile
+    const unsigned lds0 = (unsigned)(uintptr_t)(gt_lptr_t)smem;
+
+    // stage loop of a DMA-issuing wave: own pieces of stage `it` landed (younger stages stay in flight) -> barrier (everybody's
+    // pieces landed; every consumer has finished reading the slot that stage it+STAGES-1 overwrites: it was consumed in iteration
+    // it-1) -> issue stage it+STAGES-1
+    auto stage_wait = [&](int it) {
+        const int rem = NI - 1 - it;
+        if (rem >= STAGES - 2) gt_wait_vm<(STAGES - 2) * P>();
+        else if (STAGES > 3 && rem == 1) gt_wait_vm<P>();
+        else gt_wait_vm<0>();
+    };
+
+    if (LW != 0 && !consumer) {
+        // ================= loader wave =================
+        const uint4* src[P];
+        unsigned step[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const int c = lw + p * NL, kk = c / CPK, cc = c - kk * CPK;
+            if (cc < MTW) {
+                src[p] = a.xp + ((size_t)kk * a.MTs + mt0 + cc) * 64 + lane;
+                step[p] = (unsigned)(KB * a.MTs * 64);
+            } else {
+                int nt = nt0 + cc - MTW;
+                nt = nt < ntiles ? nt : ntiles - 1;   // ragged last n-group: re-reads a valid tile, its epilogue is skipped
+                src[p] = a.wp + ((size_t)nt * a.KCH + kk) * 64 + lane;
+                step[p] = (unsigned)(KB * 64);
+            }
+        }
+        auto issue = [&](int slot) {
+            if (a.db & 4) return;   // ablation (LGEN_TILE_ABLATE): no operand DMA
+            unsigned char* dst = smem + slot * STAGE_B + lw * 1024;
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                __builtin_amdgcn_global_load_lds((gt_gptr_t)src[p], (gt_lptr_t)(dst + p * NL * 1024), 16, 0, 0);
+                src[p] += step[p];
+            }
+        };
+#pragma unroll
+        for (int t = 0; t < STAGES - 1; ++t) issue(t);
+        int slot = 0;
+        for (int it = 0; it < NI; ++it) {
+            stage_wait(it);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (it + STAGES - 1 < NI) issue(slot == 0 ? STAGES - 1 : slot - 1);
+            slot = slot + 1 == STAGES ? 0 : slot + 1;
+        }
+        return;
+    }
+
+    // ================= consumer wave (LW == 0: also issues its share of the DMA) =================
+    // ---- epilogue operands first (oldest requests: they never disturb the counted waits below) ----
+    int pos = 0;
+    if constexpr (EPI == EPI_QKV) pos = *a.pos_ptr;   // per-row positions (continuous batching) stay on the skinny kernels
+    uint2 res[NTV][MTV];
+    uint4 rope[EPI == EPI_QKV ? NTV : 1];
+    if constexpr (EPI == EPI_RES) {
+#pragma unroll
+        for (int j = 0; j < NTV; ++j)
+#pragma unroll
+            for (int i = 0; i < MTV; ++i) {
+                const int nt = ntw0 + j < ntiles ? ntw0 + j : ntiles - 1;
+                res[j][i] = *(const uint2*)((const uint16_t*)a.out + D::xp_off(nt * 16 + (lane >> 4) * 4, mtw0 + i, lane & 15, a.MTs));
+            }
+    }
+    if constexpr (EPI == EPI_QKV) {
+        QkvCol qc;
+        qc.init((ntw0 < ntiles ? ntw0 : ntiles - 1) * 16 + (lane >> 4) * 4, a.d, a.hd);
+#pragma unroll
+        for (int j = 0; j < NTV; ++j) {
+            rope[j] = make_uint4(0, 0, 0, 0);
+            if (qc.sec < 2) rope[j] = *(const uint4*)(a.freqs + ((size_t)pos * (a.hd >> 1) + (qc.dd >> 1)) * 2);
+            qc.next16(a.hd, a.H);
+        }
+    }
+
+    // ---- DMA bookkeeping (LW == 0 only): piece p of this wave is chunk c = w + p * NL of a stage ----
+    const uint4* src[LW == 0 ? P : 1];
+    unsigned step[LW == 0 ? P : 1];
+    if constexpr (LW == 0) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const int c = w + p * NL, kk = c / CPK, cc = c - kk * CPK;
+            if (cc < MTW) {
+                src[p] = a.xp + ((size_t)kk * a.MTs + mt0 + cc) * 64 + lane;
+                step[p] = (unsigned)(KB * a.MTs * 64);
+            } else {
+                int nt = nt0 + cc - MTW;
+                nt = nt < ntiles ? nt : ntiles - 1;
+                src[p] = a.wp + ((size_t)nt * a.KCH + kk) * 64 + lane;
+                step[p] = (unsigned)(KB * 64);
+            }
+        }
+    }
+    auto issue = [&](int slot) {
+        if constexpr (LW == 0) {
+            unsigned char* dst = smem + slot * STAGE_B + w * 1024;
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                __builtin_amdgcn_global_load_lds((gt_gptr_t)src[p], (gt_lptr_t)(dst + p * NL * 1024), 16, 0, 0);
+                src[p] += step[p];
+            }
+        }
+    };
+
+    // ---- NORM prologue requests: norm weight (shared, every consumer writes the same bytes) + this wave's row statistics ----
+    unsigned char* s_nw = smem + STAGES * STAGE_B;
+    unsigned char* s_ssq = smem + (STAGES - 1) * STAGE_B + cw * (STAGE_B / NC);  // the last slot is idle until stage STAGES-1 is issued
+    const int q4 = a.parts >> 2;  // float4s per statistics row (launcher: parts % 4 == 0, MTV * 16 * parts * 4 <= STAGE_B / NC)
+    if constexpr (NORM) {
+        const int nwb = a.KCH * D::KC * D::ESZ;  // bytes of the norm weight
+        for (int o = 0; o < nwb; o += 1024) {
+            int off = o + lane * 16;
+            off = off < nwb - 16 ? off : nwb - 16;
+            __builtin_amdgcn_global_load_lds((gt_gptr_t)((const char*)a.nw + off), (gt_lptr_t)(s_nw + o), 16, 0, 0);
+        }
+        const int tot = MTV * 16 * q4;
+        for (int o = 0; o < tot; o += 64) {
+            int e = o + lane;
+            e = e < tot ? e : tot - 1;
+            const int row = e / q4, c4 = e - row * q4;
+            __builtin_amdgcn_global_load_lds((gt_gptr_t)(a.ssq_in + (size_t)(mtw0 * 16 + row) * LGEN_SSQ_STRIDE + c4 * 4),
+                                             (gt_lptr_t)(s_ssq + o * 16), 16, 0, 0);
+        }
+    }
+    // ---- fill the ring: stages 0 .. STAGES-2 ----
+#pragma unroll
+    for (int t = 0; t < STAGES - 1; ++t) issue(t);
+
+    // ---- RMSNorm row scales, fixed summation order of gemm_normpre.hip / ssq_rows_now (bit-identical) ----
+    float ri[MTV];
+    if constexpr (NORM) {
+        if constexpr (LW == 0) gt_wait_vm<(STAGES - 1) * P>();   // the prologue pieces are older than every stage piece
+        else gt_wait_vm<0>();
+        const int r = lane & 15, g = lane >> 4;
+        const unsigned ssq0 = lds0 + (STAGES - 1) * STAGE_B + cw * (STAGE_B / NC);
+#pragma unroll
+        for (int i = 0; i < MTV; ++i) {
+            const unsigned rowa = ssq0 + (unsigned)((i * 16 + r) * a.parts) * 4;
+            float s = 0.f;
+            if ((a.parts & 15) == 0 && a.parts <= 128) {
+                const int n4 = a.parts >> 4;
+                u32x4_t v[8];
+                gt_static_for<0, 8>([&](auto j) {
+                    constexpr int J = decltype(j)::value;
+                    v[J] = gt_lds_rd<0>(rowa + (unsigned)(g * n4 + (J < n4 ? J : 0)) * 16);
+                });
+                gt_wait_lgkm<0>();
+                gt_static_for<0, 8>([&](auto j) {
+                    constexpr int J = decltype(j)::value;
+                    gt_touch(v[J]);
+                    if (J < n4)
+                        s += (__uint_as_float(v[J][0]) + __uint_as_float(v[J][1])) + (__uint_as_float(v[J][2]) + __uint_as_float(v[J][3]));
+                });
+            } else {
+                for (int q = g; q < a.parts; q += 4) {
+                    float t;
+                    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(t) : "v"(rowa + (unsigned)q * 4) : "memory");
+                    s += t;
+                }
+            }
+            s += __shfl_xor(s, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            ri[i] = 1.0f / sqrtf(s * a.inv_k + a.eps);
+        }
+    }
+
+    f32x4_t acc[NTV][MTV];
+#pragma unroll
+    for (int j = 0; j < NTV; ++j)
+#pragma unroll
+        for (int i = 0; i < MTV; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const unsigned ldsB = lds0 + lane * 16 + (wm * MTV) * 1024;
+    const unsigned ldsA = lds0 + lane * 16 + (MTW + wn * NTV) * 1024;
+    const unsigned ldsN = lds0 + STAGES * STAGE_B + (lane >> 4) * 16;
+    constexpr int NRD = MTV + NTV + (NORM ? 1 : 0);   // LDS reads per k-chunk
+    static_assert(NRD <= 15, "lgkmcnt is a 4-bit counter");
+    int slot = 0;
+    for (int it = 0; it < NI; ++it) {
+        if constexpr (LW == 0) stage_wait(it);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (it + STAGES - 1 < NI) issue(slot == 0 ? STAGES - 1 : slot - 1);
+        const unsigned aB = ldsB + slot * STAGE_B, aA = ldsA + slot * STAGE_B, aN = ldsN + it * (KB * 64);
+        // fragments of k-chunk kk+1 are requested before the MFMAs of k-chunk kk (two register sets)
+        u32x4_t Bf[2][MTV], Af[2][NTV], Wn[2];
+        auto rd = [&](auto kk_) {
+            constexpr int KK = decltype(kk_)::value, S = KK & 1;
+            gt_static_for<0, MTV>([&](auto i) { Bf[S][decltype(i)::value] = gt_lds_rd<(KK * CPK + decltype(i)::value) * 1024>(aB); });
+            gt_static_for<0, NTV>([&](auto j) { Af[S][decltype(j)::value] = gt_lds_rd<(KK * CPK + decltype(j)::value) * 1024>(aA); });
+            if constexpr (NORM) Wn[S] = gt_lds_rd<KK * 64>(aN);
+        };
+        if (a.db & 2) { slot = slot + 1 == STAGES ? 0 : slot + 1; continue; }   // ablation: consumers only keep the barriers
+        rd(std::integral_constant<int, 0>{});
+        gt_static_for<0, KB>([&](auto kk_) {
+            constexpr int KK = decltype(kk_)::value, S = KK & 1;
+            if constexpr (KK + 1 < KB) {
+                rd(std::integral_constant<int, KK + 1>{});
+                gt_wait_lgkm<NRD>();
+            } else {
+                gt_wait_lgkm<0>();
+            }
+            gt_static_for<0, MTV>([&](auto i) { gt_touch(Bf[S][decltype(i)::value]); });
+            gt_static_for<0, NTV>([&](auto j) { gt_touch(Af[S][decltype(j)::value]); });
+            uint4 B[MTV];
+            if constexpr (NORM) {
+                gt_touch(Wn[S]);
+                const uint4 wn4 = gt_u4(Wn[S]);
+#pragma unroll
+                for (int i = 0; i < MTV; ++i) B[i] = (a.db & 1) ? gt_u4(Bf[S][i]) : D::norm_chunk(gt_u4(Bf[S][i]), ri[i], wn4);
+            } else {
+#pragma unroll
+                for (int i = 0; i < MTV; ++i) B[i] = gt_u4(Bf[S][i]);
+            }
+#pragma unroll
+            for (int i = 0; i < MTV; ++i)
+#pragma unroll
+                for (int j = 0; j < NTV; ++j) acc[j][i] = D::mma(gt_u4(Af[S][j]), B[i], acc[j][i]);
+        });
+        slot = slot + 1 == STAGES ? 0 : slot + 1;
+    }
+
+    // ---- epilogue: this wave's NTV x MTV tiles ----
+    if constexpr (EPI == EPI_QKV) {
+        QkvCol qc;
+        qc.init((ntw0 < ntiles ? ntw0 : ntiles - 1) * 16 + (lane >> 4) * 4, a.d, a.hd);
+        const int r = lane & 15;
+#pragma unroll
+        for (int j = 0; j < NTV; ++j) {
+            if (ntw0 + j < ntiles) {
+#pragma unroll
+                for (int i = 0; i < MTV; ++i) {
+                    const int m = (mtw0 + i) * 16 + r;
+                    const f32x4_t v = acc[j][i];
+                    float x0 = D::rnd(v[0]), x1 = D::rnd(v[1]), x2 = D::rnd(v[2]), x3 = D::rnd(v[3]);
+                    if (qc.sec < 2) {  // 2-D RoPE on interleaved (even, odd) pairs, fp32, one rounding (gpt.py:420-430)
+                        const float fx = __uint_as_float(rope[j].x), fy = __uint_as_float(rope[j].y);
+                        const float fz = __uint_as_float(rope[j].z), fw = __uint_as_float(rope[j].w);
+                        const float y0 = x0 * fx - x1 * fy, y1 = x1 * fx + x0 * fy;
+                        const float y2 = x2 * fz - x3 * fw, y3 = x3 * fz + x2 * fw;
+                        x0 = y0; x1 = y1; x2 = y2; x3 = y3;
+                    }
+                    if (m < a.M) {
+                        if (qc.sec == 0) {
+                            D::st4(a.out, ((size_t)m * a.H + qc.head) * a.hdp + qc.dd, x0, x1, x2, x3);
+                        } else {
+                            void* cache = qc.sec == 1 ? a.kc : a.vc;
+                            D::st4(cache, (((size_t)m * a.H + qc.head) * a.S8 + pos) * a.kvs + qc.dd, x0, x1, x2, x3);
+                        }
+                    }
+                }
+            }
+            qc.next16(a.hd, a.H);
+        }
+    } else if constexpr (EPI == EPI_SWIGLU) {
+#pragma unroll
+        for (int j = 0; j < NTV; j += 2) {
+            if (ntw0 + j < ntiles) {
+#pragma unroll
+                for (int i = 0; i < MTV; ++i)
+                    epilogue<D, EPI>(a, ntw0 + j, mtw0 + i, lane, acc[j][i], acc[j + 1][i], make_uint4(0, 0, 0, 0), 0);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NTV; ++j) {
+            if (ntw0 + j < ntiles) {
+#pragma unroll
+                for (int i = 0; i < MTV; ++i) {
+                    uint4 aux = make_uint4(0, 0, 0, 0);
+                    if constexpr (EPI == EPI_RES) { aux.x = res[j][i].x; aux.y = res[j][i].y; }
+                    epilogue<D, EPI>(a, ntw0 + j, mtw0 + i, lane, acc[j][i], acc[j][i], aux, 0);
+                }
+            }
+        }
+    }
+}
+
+// ---- launch table ---------------------------------------------------------------------------------------------------------
+template <typename D, int WM, int WN, int MTV, int NTV, int KB, int STAGES, int EPI, bool NORM, int LW>
+static int gt_launch(const GemmArgs& a, hipStream_t st) {
+    constexpr int NW = WM * WN, MTW = WM * MTV, NTW = WN * NTV, CPS = KB * (MTW + NTW), STAGE_B = CPS * 1024;
+    if (a.MTs % MTW || a.KCH % KB || a.KCH / KB < STAGES - 1) return LGEN_ERR_UNSUPPORTED;
+    size_t lds = (size_t)STAGES * STAGE_B;
+    if (NORM) {
+        if (a.parts % 4 || (size_t)MTV * 16 * a.parts * 4 > (size_t)STAGE_B / NW) return LGEN_ERR_UNSUPPORTED;
+        lds += ((size_t)a.KCH * D::KC * D::ESZ + 1023) / 1024 * 1024;
+    }
+    if (lds > 160 * 1024) return LGEN_ERR_UNSUPPORTED;
+    const int ntiles = a.N / 16;
+    const int gx = (ntiles + NTW - 1) / NTW, gy = a.MTs / MTW;
+    auto kern = gemm_tile_kernel<D, WM, WN, MTV, NTV, KB, STAGES, EPI, NORM, LW>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(kern, dim3(8 * ((gx + 7) / 8) * gy), dim3(64 * (NW + LW)), lds, st, a);
+    LGEN_CHECK_LAUNCH();
+    return 0;
+}
+
+// shapes (WM, WN, MTV, NTV, KB, STAGES, LW) with an instantiation; X(...) is expanded per (EPI, NORM) below
+#define GT_SHAPES_NORM(X)                                                                                        \
+    X(4, 1, 1, 3, 4, 4, 4) X(4, 1, 1, 4, 4, 4, 4) X(4, 1, 1, 6, 2, 4, 4) X(4, 1, 1, 6, 4, 3, 4) X(4, 1, 1, 8, 2, 4, 4) \
+    X(4, 1, 2, 4, 2, 4, 4) X(4, 1, 2, 6, 2, 4, 4) X(4, 1, 2, 8, 2, 4, 4) X(4, 1, 1, 2, 4, 4, 4) X(4, 1, 1, 3, 4, 4, 0)
+#define GT_SHAPES_PLAIN(X)                                                                                       \
+    X(2, 2, 1, 1, 4, 4, 4) X(2, 2, 1, 2, 4, 4, 4) X(2, 2, 2, 1, 4, 4, 4) X(2, 2, 2, 2, 4, 4, 4) X(2, 2, 2, 2, 2, 4, 4) \
+    X(4, 1, 1, 2, 4, 4, 4) X(2, 2, 1, 1, 4, 4, 0) X(2, 2, 4, 1, 4, 4, 4) X(2, 2, 4, 2, 2, 4, 4)
+
+template <typename D, int EPI, bool NORM>
+static int gt_dispatch(const GemmArgs& a, int wm, int wn, int mtv, int ntv, int kb, int stages, int lw, hipStream_t st) {
+#define GT_CASE(WM_, WN_, MTV_, NTV_, KB_, ST_, LW_)                                                                 \
+    if (wm == WM_ && wn == WN_ && mtv == MTV_ && ntv == NTV_ && kb == KB_ && stages == ST_ && lw == LW_) {            \
+        if constexpr (EPI == EPI_SWIGLU && (NTV_ % 2)) return LGEN_ERR_UNSUPPORTED;                                   \
+        else return gt_launch<D, WM_, WN_, MTV_, NTV_, KB_, ST_, EPI, NORM, LW_>(a, st);                               \
+    }
+    if constexpr (NORM) {
+        GT_SHAPES_NORM(GT_CASE)
+    } else {
+        GT_SHAPES_PLAIN(GT_CASE)
+    }
+#undef GT_CASE
+    return LGEN_ERR_UNSUPPORTED;
+}
+
+static int gt_ablate() {   // development switch: bit 0 no RMSNorm VALU work, bit 1 no LDS reads / MFMAs, bit 2 no operand DMA
+    const char* e = getenv("LGEN_TILE_ABLATE");
+    return e ? atoi(e) : 0;
+}
+
+static int gt_dispatch_epi(const GemmArgs& a, int epi, int wm, int wn, int mtv, int ntv, int kb, int stages, int lw, hipStream_t st) {
+    if (a.nw) {
+        if (!a.ssq_in || a.parts < 1) return LGEN_ERR_BAD_ARG;
+        switch (epi) {
+            case EPI_QKV: return gt_dispatch<BF16, EPI_QKV, true>(a, wm, wn, mtv, ntv, kb, stages, lw, st);
+            case EPI_SWIGLU: return gt_dispatch<BF16, EPI_SWIGLU, true>(a, wm, wn, mtv, ntv, kb, stages, lw, st);
+            case EPI_ROWS: return gt_dispatch<BF16, EPI_ROWS, true>(a, wm, wn, mtv, ntv, kb, stages, lw, st);
+            default: return LGEN_ERR_UNSUPPORTED;
+        }
+    }
+    switch (epi) {
+        case EPI_RES: return gt_dispatch<BF16, EPI_RES, false>(a, wm, wn, mtv, ntv, kb, stages, lw, st);
+        default: return LGEN_ERR_UNSUPPORTED;
+    }
+}
+
+// LGEN_GEMM_TILE_* entry points (include/lgen.h): same operand contract as lgen_gemm / lgen_gemm_qkv_rope, the workgroup shape
+// is explicit.  bf16 storage only; LGEN_ERR_UNSUPPORTED for a shape without an instantiation (the caller picks another one).
+extern "C" int lgen_gemm_tile(const void* wp, const void* xp, void* out, int M, int MTs, int N, int K, int epilogue_kind, int dtype,
+                              int wm, int wn, int mtv, int ntv, int kb, int stages, int lw, const void* norm_w, const float* ssq_in,
+                              int ssq_parts, float eps, float* ssq_out, void* stream) {
+    if (dtype != LGEN_BF16) return LGEN_ERR_UNSUPPORTED;
+    if (N % 16 || K % 32 || M > MTs * 16 || M < 1) return LGEN_ERR_BAD_ARG;
+    if ((norm_w && (ssq_parts < 1 || ssq_parts > LGEN_SSQ_STRIDE)) || (ssq_out && N / 16 > LGEN_SSQ_STRIDE)) return LGEN_ERR_BAD_ARG;
+    if (ssq_out && epilogue_kind != LGEN_EPI_RES) return LGEN_ERR_BAD_ARG;
+    if (epilogue_kind == LGEN_EPI_QKV) return LGEN_ERR_BAD_ARG;
+    GemmArgs a{};
+    a.wp = (const uint4*)wp; a.xp = (const uint4*)xp; a.out = out;
+    a.N = N; a.KCH = K / 32; a.MTs = MTs; a.M = M;
+    a.nw = (const uint4*)norm_w; a.ssq_in = ssq_in; a.parts = ssq_parts; a.eps = eps; a.inv_k = 1.0f / (float)K;
+    a.ssq_out = ssq_out;
+    a.passes = 1;
+    a.db = gt_ablate();
+    return gt_dispatch_epi(a, epilogue_kind, wm, wn, mtv, ntv, kb, stages, lw, (hipStream_t)stream);
+}
+
+extern "C" int lgen_gemm_qkv_rope_tile(const void* wp, const void* xp, void* q_out, void* k_cache, void* v_cache, const float* freqs,
+                                       const int* pos_ptr, int M, int MTs, int d, int n_head, int hd, int hdp, int S8,
+                                       int kv_row_stride, int dtype, int wm, int wn, int mtv, int ntv, int kb, int stages, int lw,
+                                       const void* norm_w, const float* ssq_in, int ssq_parts, float eps, void* stream) {
+    if (dtype != LGEN_BF16) return LGEN_ERR_UNSUPPORTED;
+    if (d % 32 || (3 * d) % 16 || hd % 4 || hd < 16 || d != n_head * hd || M > MTs * 16 || M < 1) return LGEN_ERR_BAD_ARG;
+    if (norm_w && (ssq_parts < 1 || ssq_parts > LGEN_SSQ_STRIDE)) return LGEN_ERR_BAD_ARG;
+    GemmArgs a{};
+    a.wp = (const uint4*)wp; a.xp = (const uint4*)xp; a.out = q_out; a.kc = k_cache; a.vc = v_cache;
+    a.freqs = freqs; a.pos_ptr = pos_ptr; a.pos_stride = 0;
+    a.N = 3 * d; a.KCH = d / 32; a.MTs = MTs; a.M = M;
+    a.d = d; a.hd = hd; a.hdp = hdp; a.H = n_head; a.S8 = S8;
+    a.kvs = kv_row_stride > 0 ? kv_row_stride : hdp;
+    if (a.kvs < hdp) return LGEN_ERR_BAD_ARG;
+    a.nw = (const uint4*)norm_w; a.ssq_in = ssq_in; a.parts = ssq_parts; a.eps = eps; a.inv_k = 1.0f / (float)d;
+    a.passes = 1;
+    a.db = gt_ablate();
+    if (!norm_w) return LGEN_ERR_UNSUPPORTED;
+    return gt_dispatch<BF16, EPI_QKV, true>(a, wm, wn, mtv, ntv, kb, stages, lw, (hipStream_t)stream);
+}

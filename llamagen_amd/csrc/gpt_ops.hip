@@ -251,8 +251,6 @@ struct AttnArgs {
     float sf;            // sqrt(1/sqrt(hd))
     int kvs;             // elements between consecutive cache rows (hdp, or 2*hdp for an interleaved K|V slab)
     int mask_len;        // only keys < mask_len consult the mask row (t2i: the caption prefix); the rest is pure causal
-    const char* pf;      // next kernel's weights (wo), see prefetch_lines in gemm_epilogue.h
-    long long pf_bytes;
 };
 
 // HPW (round 3): (batch row, head) pairs per workgroup.  At 256 chain rows the grid is 4096 (b, h) pairs; dispatching that many
@@ -278,7 +276,6 @@ __global__ __launch_bounds__(64 * ATT_NW * HPW, (ATT_CH <= 2 ? 4 : 2)) void attn
     const uint4* vp = (const uint4*)a.vc + rowbase * rpr + part;
     const int smax = a.S8 - 1;
 
-    const unsigned pf_token = prefetch_lines(a.pf, a.pf_bytes, blockIdx.x * ATT_NW * HPW + wvall, gridDim.x * ATT_NW * HPW, lane);
     uint4 k0[ATT_CH], v0[ATT_CH], k1[ATT_CH], v1[ATT_CH];
 #define ATT_LOAD(KB, VB, g)                                                 \
     {                                                                       \
@@ -347,7 +344,6 @@ __global__ __launch_bounds__(64 * ATT_NW * HPW, (ATT_CH <= 2 ? 4 : 2)) void attn
     }
 #undef ATT_LOAD
 #undef ATT_COMPUTE
-    prefetch_retire(a.pf, pf_token);
     // combine the KPL key groups of this wave (lanes with equal `part`)
 #pragma unroll
     for (int o = LPK; o < 64; o <<= 1) {
@@ -377,22 +373,158 @@ __global__ __launch_bounds__(64 * ATT_NW * HPW, (ATT_CH <= 2 ? 4 : 2)) void attn
     }
 }
 
-// variants 6 / 7 (round 3): (2, 2) with 2 / 4 heads of a row per workgroup (wide chains: fewer workgroups to dispatch).
-// variant (ATT_CH K/V loads per buffer, waves per (b, h) workgroup): 2 = default (2, 2): 128-thread workgroups,
-// every workgroup of a B2 x H = 1024 grid resident at once, lowest fixed cost (4.4 us at kv_len 1 vs 6.1 us with
-// 4 waves) and the same 6.4 TB/s incremental rate at long kv_len; 1 = (2, 4); 0 = (4, 4); 3 = (4, 2); 4 = (2, 1); 5 = (4, 1)
-static int g_attn_variant = 2;
-// K/V loads are non-temporal (ldg_nt in ATT_LOAD): every cache row is read once per step, and keeping 75-150 MB per layer out
-// of the memory-side cache leaves the (chain-shared) weights there: 26.5 vs 28.5 us at kv_len 576, 71.6 vs 68.6 img/s.  Fixed
-// at compile time: a per-load run-time choice costs the compiler its count of loads in flight (vmcnt(0) before every compute).
-extern "C" int lgen_set_attn_variant(int v) { g_attn_variant = v; return 0; }
+// ---- persistent form (round 4, variant 8) ---------------------------------------------------------------------------------
+// Same arithmetic per (batch row, head) as attn_decode_kernel with one wave per item (the wave-level online softmax of variants
+// 4 / 5: every group of CH x KPL keys updates one wave-uniform running maximum, so the result does not depend on how many waves
+// share the chip), different schedule: a fixed grid of NWV-wave workgroups, ONE per CU, whose waves each walk whole (b, h) items
+// gw, gw + total_waves, ... as ONE flat stream of K/V groups -- the loads of the next group (of the next item, at an item
+// boundary) are in flight while the current group is reduced, 2 x 2 x CH KiB per wave.  Why (measured, round 4):
+//   * at 256 rows attn_decode_kernel is 2048 workgroups of 4 waves that fill every SIMD to 5 waves: ~9 us of a 52 us launch are
+//     dispatch + the cold first round trip of every workgroup, and
+//   * while such a grid drains, a GEMM / conv workgroup of ANOTHER chain (2 waves on all four SIMDs + > 100 KB of LDS at once)
+//     cannot be placed -- small workgroups keep taking the slots that free up -- so chains in flight barely overlap
+//     (three 256-row chains: 105 img/s against 85 with one).  Eight resident waves per CU at <= 128 VGPRs leave 256 registers per
+//     SIMD and all of the LDS to whatever else is in flight.
+// No LDS, no barriers; one (pos, kv_len) for all rows (generate()); per-row positions keep attn_decode_kernel.
+template <typename D, int LPK, int CH, int NWV>
+__global__ __launch_bounds__(64 * NWV) void attn_decode_persist_kernel(AttnArgs a, int items, int total_waves) {
+    constexpr int KPL = 64 / LPK;            // keys per wave-load
+    constexpr int EPL = D::EPL;
+    constexpr int GK = CH * KPL;             // keys per group
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * NWV + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (gw >= items) return;
+    const int part = lane % LPK, kin = lane / LPK;
+    const int lpr = a.hdp / EPL;             // 16-byte pieces per key row (== LPK)
+    const int rpr = a.kvs / EPL;             // 16-byte pieces between consecutive rows of one cache
+    const int smax = a.S8 - 1;
+    const uint4* const dummy = (const uint4*)a.q + part;   // where the look-ahead loads past the last item point (finite, L2-hot)
 
+    uint4 k0[CH], v0[CH], k1[CH], v1[CH];
+    auto load = [&](uint4 (&KB)[CH], uint4 (&VB)[CH], int item, int g) {
+        const bool live = item < items;      // wave-uniform; loads stay unconditional so that the waits stay counted
+        const uint4* kp = live ? (const uint4*)a.kc + (size_t)item * a.S8 * rpr + part : dummy;
+        const uint4* vp = live ? (const uint4*)a.vc + (size_t)item * a.S8 * rpr + part : dummy;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            int kk = g * GK + j * KPL + kin;
+            kk = kk < smax ? kk : smax;
+            const size_t o = live ? (size_t)kk * rpr : 0;
+            KB[j] = ldg_nt(kp + o);
+            VB[j] = ldg_nt(vp + o);
+        }
+    };
+    // the first group and q of the first item are requested before the position is known
+    load(k0, v0, gw, 0);
+    uint4 qv = ((const uint4*)a.q)[(size_t)gw * lpr + part];
+    const int pos = *a.pos_ptr;
+    const int kvlen = pos + 1;
+    const int ngroups = (kvlen + GK - 1) / GK;
+    int li = gw, lg = 0;                      // load cursor: the group after the one just requested
+    auto advance = [&](int& item, int& g) {
+        if (++g == ngroups) { g = 0; item += total_waves; }
+    };
+    advance(li, lg);
+
+    int ci = gw, cg = 0;                      // compute cursor
+    float qf[EPL], m_run = -1e30f, l_run = 0.f, acc[EPL];
+    uint4 qn = qv;
+    auto begin_item = [&]() {
+        D::unpack(qn, qf);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) { qf[e] *= a.sf; acc[e] = 0.f; }
+        m_run = -1e30f; l_run = 0.f;
+        const int nxt = ci + total_waves;     // q of the following item: one whole item ahead
+        qn = ((const uint4*)a.q)[(size_t)(nxt < items ? nxt : ci) * lpr + part];
+    };
+    begin_item();
+    auto compute = [&](const uint4 (&KB)[CH], const uint4 (&VB)[CH]) {
+        const unsigned char* pm = a.mask ? a.mask + ((size_t)(ci / a.H) * a.S8 + pos) * a.S8 : nullptr;
+        float s[CH];
+        float tmax = -1e30f;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int key = cg * GK + j * KPL + kin;
+            float kf[EPL];
+            D::unpack(KB[j], kf);
+            float dot = 0.f;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) dot = fmaf(qf[e], kf[e] * a.sf, dot);
+#pragma unroll
+            for (int o = 1; o < LPK; o <<= 1) dot += __shfl_xor(dot, o, 64);
+            bool vis = key < kvlen;
+            if (pm && vis && key < a.mask_len) vis = pm[key] != 0;
+            s[j] = vis ? dot : -1e30f;
+            tmax = fmaxf(tmax, s[j]);
+        }
+#pragma unroll
+        for (int o = LPK; o < 64; o <<= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, o, 64));
+        const float m_new = fmaxf(m_run, tmax);
+        const float scale = D::fexp(m_run - m_new);
+        l_run *= scale;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) acc[e] *= scale;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const float p = s[j] > -1e29f ? D::fexp(s[j] - m_new) : 0.f;
+            l_run += p;
+            float vf[EPL];
+            D::unpack(VB[j], vf);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) acc[e] = fmaf(p, vf[e], acc[e]);
+        }
+        m_run = m_new;
+    };
+    auto end_group = [&]() {                  // returns false when this wave has no item left
+        if (++cg < ngroups) return true;
+        // item done: combine the KPL key groups of the wave (lanes with equal `part`), normalise, store
+#pragma unroll
+        for (int o = LPK; o < 64; o <<= 1) {
+            l_run += __shfl_xor(l_run, o, 64);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
+        }
+        if (lane < LPK) {
+            const int b = ci / a.H, h = ci - b * a.H;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                const int t = lane * EPL + e;
+                if (t < a.hd) D::st(a.out, D::xp_off(h * a.hd + t, b >> 4, b & 15, a.MTs), acc[e] / l_run);
+            }
+        }
+        cg = 0;
+        ci += total_waves;
+        if (ci >= items) return false;
+        begin_item();
+        return true;
+    };
+    while (true) {
+        load(k1, v1, li, lg);
+        advance(li, lg);
+        compute(k0, v0);
+        if (!end_group()) break;
+        load(k0, v0, li, lg);
+        advance(li, lg);
+        compute(k1, v1);
+        if (!end_group()) break;
+    }
+}
+
+// Kernel variants (explicit `variant` argument of lgen_attn_decode; -1 = the library's choice by shape):
+//   (K/V loads per buffer, waves per (b, h) workgroup): 0 = (4, 4); 1 = (2, 4); 2 = (2, 2): 128-thread workgroups, lowest fixed cost at
+//   <= 128 rows (4.4 us at kv_len 1 vs 6.1 us with 4 waves, same 6.4 TB/s incremental rate); 3 = (4, 2); 4 = (2, 1); 5 = (4, 1);
+//   6 / 7 (round 3): (2, 2) with 2 / 4 heads of a row per workgroup (fewer workgroups to dispatch at >= 256 rows);
+//   8 .. 13 (round 4): the persistent form, (loads per buffer, waves per workgroup) = 8: (4, 8); 9: (4, 8) x two workgroups per CU;
+//   10: (4, 4); 11: (2, 8); 12: (2, 4); 13: (1, 8) -- one position for all rows only.
+// K/V loads are non-temporal (ldg_nt): every cache row is read once per step, and keeping 75-150 MB per layer out of the
+// memory-side cache leaves the (chain-shared) weights there: 26.5 vs 28.5 us at kv_len 576, 71.6 vs 68.6 img/s.  Fixed at
+// compile time: a per-load run-time choice costs the compiler its count of loads in flight (vmcnt(0) before every compute).
 static int attn_decode_impl(const void* q, const void* k_cache, const void* v_cache, void* out_packed,
                             const int* pos_ptr, int pos_stride, const unsigned char* mask, int mask_len, int B2, int MTs,
-                            int n_head, int hd, int hdp, int S8, int kv_row_stride, int dtype, void* stream) {
+                            int n_head, int hd, int hdp, int S8, int kv_row_stride, int dtype, int variant_arg, void* stream) {
     AttnArgs a{q, k_cache, v_cache, out_packed, pos_ptr, pos_stride, mask, n_head, hd, hdp, S8, MTs, 0.f,
-               kv_row_stride > 0 ? kv_row_stride : hdp, mask_len > 0 ? mask_len : S8, nullptr, 0};
-    lgen_take_prefetch_hint(&a.pf, &a.pf_bytes);
+               kv_row_stride > 0 ? kv_row_stride : hdp, mask_len > 0 ? mask_len : S8};
+    if (variant_arg < -1 || variant_arg > 13) return LGEN_ERR_BAD_ARG;
     a.sf = sqrtf(1.0f / sqrtf((float)hd));
     hipStream_t st = (hipStream_t)stream;
     const int epl = dtype != LGEN_F32 ? 8 : 4;
@@ -401,8 +533,51 @@ static int attn_decode_impl(const void* q, const void* k_cache, const void* v_ca
     const int lpk = hdp / epl;
     // default variant 2; chains of >= 256 rows put two heads of a row into a workgroup (variant 6: 49.8 vs 50.7 us average launch
     // at 256 rows, 27.3 vs 27.0 at 128: tools/attn_sweep.py, profiles/r03_attn_sweep.log)
-    const int variant = (g_attn_variant == 2 && B2 >= 256 && n_head % 2 == 0) ? 6 : g_attn_variant;
+    // library's choice (variant_arg == -1): variant 2 below 256 rows; chains of >= 256 rows at one position take the persistent form with 4 waves x 16 KiB in flight per
+    // CU (variant 10).  Alone it is ~6 % slower than variant 6 (54.3 vs 51.1 us per average launch at 256 rows: one wave per SIMD
+    // has nothing to hide its own VALU latency behind), but with two chains in flight the bench gains 8 % (110.1 -> 119.0 img/s at
+    // 512-row chains, gpurun_out/attn_ab3.log): 64 KB per CU in flight instead of 160 leaves the HBM queue short enough for the other
+    // chain's latency-bound kernels, and 4 resident waves leave every SIMD room for them (tools/overlap_probe.py: the GEMM chain
+    // hidden under an attention chain 0.30 -> 0.57).  Per-row positions (continuous batching): variant 6 (two heads per workgroup).
+    int variant = variant_arg;
+    if (variant < 0) variant = B2 >= 256 ? (pos_stride == 0 ? 10 : (n_head % 2 == 0 ? 6 : 2)) : 2;
+    if (variant >= 8 && pos_stride == 0) {
+        // persistent form, (K/V loads per buffer CH, waves per workgroup) = 8: (4, 8), one workgroup per CU; 9: (4, 8) x two per CU;
+        // 10: (4, 4); 11: (2, 8); 12: (2, 4); 13: (1, 8).  Bytes in flight per CU = waves x 4 x CH KiB: what the HBM queue holds
+        // beyond the bandwidth-delay product (~10 MB chip-wide) only adds latency for every kernel that shares the chip.
+        static int n_cu = 0;
+        if (!n_cu) {
+            int dev = 0, v = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 256;
+            n_cu = v > 0 ? v : 256;
+        }
+        const int items = B2 * n_head;
+        const int nwv = (variant == 10 || variant == 12) ? 4 : 8;
+        const int ch = variant <= 10 ? 4 : (variant <= 12 ? 2 : 1);
+        int wgs = n_cu * (variant == 9 ? 2 : 1);
+        if (wgs * nwv > items) wgs = (items + nwv - 1) / nwv;
+        const int total_waves = wgs * nwv;
+#define LGEN_ATTP(DT, L)                                                                                                   \
+        do {                                                                                                               \
+            if (ch == 4 && nwv == 8) hipLaunchKernelGGL((attn_decode_persist_kernel<DT, L, 4, 8>), dim3(wgs), dim3(512), 0, st, a, items, total_waves); \
+            else if (ch == 4) hipLaunchKernelGGL((attn_decode_persist_kernel<DT, L, 4, 4>), dim3(wgs), dim3(256), 0, st, a, items, total_waves);        \
+            else if (ch == 2 && nwv == 8) hipLaunchKernelGGL((attn_decode_persist_kernel<DT, L, 2, 8>), dim3(wgs), dim3(512), 0, st, a, items, total_waves); \
+            else if (ch == 2) hipLaunchKernelGGL((attn_decode_persist_kernel<DT, L, 2, 4>), dim3(wgs), dim3(256), 0, st, a, items, total_waves);        \
+            else hipLaunchKernelGGL((attn_decode_persist_kernel<DT, L, 1, 8>), dim3(wgs), dim3(512), 0, st, a, items, total_waves);                     \
+        } while (0)
+        if (dtype == LGEN_BF16 && lpk == 8) LGEN_ATTP(BF16, 8);
+        else if (dtype == LGEN_BF16 && lpk == 16) LGEN_ATTP(BF16, 16);
+        else if (dtype == LGEN_F16 && lpk == 8) LGEN_ATTP(F16, 8);
+        else if (dtype == LGEN_F16 && lpk == 16) LGEN_ATTP(F16, 16);
+        else if (dtype == LGEN_F32 && lpk == 16) LGEN_ATTP(F32, 16);
+        else if (dtype == LGEN_F32 && lpk == 32) LGEN_ATTP(F32, 32);
+        else return LGEN_ERR_BAD_ARG;
+#undef LGEN_ATTP
+        LGEN_CHECK_LAUNCH();
+        return 0;
+    }
     const int hpw = variant == 6 ? 2 : (variant == 7 ? 4 : 1);
+    if (variant >= 8) return LGEN_ERR_UNSUPPORTED;   // per-row positions: the persistent form has one kv_len for all rows
     if (n_head % hpw) return LGEN_ERR_BAD_ARG;
     const int nw = variant >= 6 ? 2 : (variant >= 4 ? 1 : (variant >= 2 ? 2 : 4));
     dim3 grid(B2 * n_head / hpw), block(64 * nw * hpw);
@@ -431,16 +606,16 @@ static int attn_decode_impl(const void* q, const void* k_cache, const void* v_ca
 
 extern "C" int lgen_attn_decode(const void* q, const void* k_cache, const void* v_cache, void* out_packed,
                                 const int* pos_ptr, const unsigned char* mask, int mask_len, int B2, int MTs,
-                                int n_head, int hd, int hdp, int S8, int kv_row_stride, int dtype, void* stream) {
+                                int n_head, int hd, int hdp, int S8, int kv_row_stride, int dtype, int variant, void* stream) {
     return attn_decode_impl(q, k_cache, v_cache, out_packed, pos_ptr, 0, mask, mask_len, B2, MTs, n_head, hd, hdp, S8,
-                            kv_row_stride, dtype, stream);
+                            kv_row_stride, dtype, variant, stream);
 }
 
 extern "C" int lgen_attn_decode_rows(const void* q, const void* k_cache, const void* v_cache, void* out_packed,
                                      const int* row_pos, const unsigned char* mask, int mask_len, int B2, int MTs,
-                                     int n_head, int hd, int hdp, int S8, int kv_row_stride, int dtype, void* stream) {
+                                     int n_head, int hd, int hdp, int S8, int kv_row_stride, int dtype, int variant, void* stream) {
     return attn_decode_impl(q, k_cache, v_cache, out_packed, row_pos, 1, mask, mask_len, B2, MTs, n_head, hd, hdp, S8,
-                            kv_row_stride, dtype, stream);
+                            kv_row_stride, dtype, variant, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -814,7 +989,7 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const uint16_t* 
 }
 
 static int g_prefill_mfma = 1;
-extern "C" int lgen_set_prefill_mfma(int v) { g_prefill_mfma = v ? 1 : 0; return 0; }
+extern "C" int lgen_debug_set_prefill_mfma(int v) { g_prefill_mfma = v ? 1 : 0; return 0; }
 
 template <typename D>
 static int launch_attn_prefill_tiled(const void* q_rows, const void* k_cache, const void* v_cache, void* out_packed,

@@ -144,7 +144,7 @@ extern "C" int lgen_vq_argmin(const float* z_nchw, const float* cb_norm, const f
 // ---------------------------------------------------------------------------------------------
 #define GN_THREADS 256
 static int g_vq_nt = 0;
-extern "C" int lgen_set_vq_nt(int v) { g_vq_nt = v ? 1 : 0; return 0; }
+extern "C" int lgen_debug_set_vq_nt(int v) { g_vq_nt = v ? 1 : 0; return 0; }
 int lgen_vq_nt() { return g_vq_nt; }
 
 __global__ __launch_bounds__(GN_THREADS) void gn_partial_kernel(const float* __restrict__ x, double* __restrict__ part, int hw,

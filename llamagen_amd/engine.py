@@ -61,6 +61,38 @@ def precompute_freqs_cis_2d(grid_size: int, n_elem: int, base: float, cls_token_
     return torch.cat([torch.zeros(cls_token_num, n_elem // 2, 2), cache])
 
 
+# Big-M tile family (csrc/gemm_tile.hip): workgroup shapes (wm, wn, mtv, ntv, kb, stages, lw) per decode GEMM, keyed by the smallest
+# MTs (rows / 16) they serve.  Per-CU tile area ~ rows x N / 256 CUs, as square as the wave arrangement allows (the feed per CU is the
+# tile perimeter x K); measured on MI355X with tools/gemm_tile_sweep.py (gpurun_out/tile_sweep2/3.log, GPT-L, us per launch,
+# skinny -> tile): 256 rows wqkv 10.2 -> 9.8, wo 4.85 -> 4.1, w1||w3 13.1 -> 10.6, w2 7.8 -> 7.7, lm_head 23.2 -> 20.9; 512 rows
+# 16.3 -> 12.9, 7.7 -> 5.1, 20.3 -> 18.9, 9.5 -> 7.9, 39.0 -> 37.8; 1024 rows 51.6 -> 22.1, 13.0 -> 6.6, 34.1 -> 35.0, 16.9 -> 11.5,
+# 71.1 -> 68.8.  The 256- and 640-row tables are what tests/test_gpu_headline.py holds to the oracle end to end and what bench.py
+# accepts as a tested schedule; every shape of every table is held to the oracle at kernel level (and all shapes agree bit for bit).
+TILE_SCHEDULES = {
+    16: {"qkv": (4, 1, 1, 3, 4, 4, 4), "wo": (2, 2, 1, 1, 4, 4, 4), "w13": (4, 1, 1, 6, 4, 3, 4), "w2": (2, 2, 1, 1, 4, 4, 4),
+         "head": (4, 1, 2, 8, 2, 4, 4)},
+    32: {"qkv": (4, 1, 1, 6, 4, 3, 4), "wo": (2, 2, 2, 1, 4, 4, 4), "w13": (4, 1, 2, 8, 2, 4, 4), "w2": (2, 2, 2, 1, 4, 4, 4),
+         "head": (4, 1, 2, 8, 2, 4, 4)},
+    # 640 rows (`bench.py --steps 20`: two chains of ten batches), gpurun_out/tile_sweep4.log: a launch is whole ROUNDS of <= 256
+    # workgroups, so the shapes are the ones that fill one round -- wqkv 240 workgroups 16.0 us (22.1 with the 512-row shape: 320
+    # workgroups = two rounds), wo 160 / 6.3 (8.1), w1||w3 220 / 19.2, w2 160 / 10.9 (14.6), lm_head 640 / 52.2
+    40: {"qkv": (4, 1, 1, 8, 2, 4, 4), "wo": (2, 2, 2, 2, 4, 4, 4), "w13": (4, 1, 2, 8, 2, 4, 4), "w2": (2, 2, 2, 2, 4, 4, 4),
+         "head": (4, 1, 2, 8, 2, 4, 4)},
+    64: {"qkv": (4, 1, 2, 8, 2, 4, 4), "wo": (2, 2, 2, 2, 4, 4, 4), "w13": (4, 1, 2, 8, 2, 4, 4), "w2": (2, 2, 2, 2, 4, 4, 4),
+         "head": (4, 1, 2, 8, 2, 4, 4)},
+}
+TILE_SCHEDULE_EXACT = (40,)        # keys that serve exactly that MTs; the others serve every MTs from the key up to the next one
+TESTED_TILE_SCHEDULES = (16, 40)   # keys of TILE_SCHEDULES with an end-to-end oracle test (tests/test_gpu_headline.py)
+
+
+def tile_schedule_key(mts: int):
+    """Key of TILE_SCHEDULES that serves a chain of `mts` m-tiles (None: below 256 rows, the skinny kernels)."""
+    if mts in TILE_SCHEDULE_EXACT:
+        return mts
+    keys = [k for k in TILE_SCHEDULES if k not in TILE_SCHEDULE_EXACT and k <= mts]
+    return max(keys) if keys else None
+
+
 class PackedWeights:
     """MFMA-fragment-packed copies of a Transformer's parameters (see lgen.h for the layouts)."""
 
@@ -99,8 +131,8 @@ class DecodeEngine:
         if dtype not in (torch.bfloat16, torch.float32, torch.float16):
             raise NotImplementedError(f"the HIP engine implements --precision bf16, fp16 and none (fp32), not {dtype}")
         self.lib = L.lib()
-        if os.environ.get("LGEN_ATTN_VARIANT") is not None:  # tuning knob, see lgen_set_attn_variant in lgen.h
-            self.lib.lgen_set_attn_variant(int(os.environ["LGEN_ATTN_VARIANT"]))
+        # decode-attention kernel variant: -1 = the library's choice by shape (lgen.h); LGEN_ATTN_VARIANT=n pins one (development)
+        self.attn_variant = int(os.environ.get("LGEN_ATTN_VARIANT", "-1"))
         self.dev = model.tok_embeddings.weight.device
         self.dtype = dtype
         self.dt = {torch.bfloat16: L.BF16, torch.float32: L.F32, torch.float16: L.F16}[dtype]
@@ -120,6 +152,11 @@ class DecodeEngine:
         for n in (self.d, self.F):
             if n % 32:
                 raise NotImplementedError("model dims must be multiples of 32")
+        if dtype != torch.float32 and self.d > 4096 and not (self.d // 32 % 8 == 0 and 3 <= self.d // 32 // 8 <= 6):
+            # the stand-alone 16-bit RMSNorm kernel holds a row in registers up to 4096 columns (lgen_rmsnorm); every registry
+            # model is <= 3200 wide -- say so here instead of failing in the middle of a decode chain
+            raise NotImplementedError(f"dim {self.d} > 4096 with {dtype}: the stand-alone RMSNorm kernel covers 16-bit rows up to 4096 "
+                                      "columns (use --precision none, or a model width the fused-norm GEMMs take)")
         if self.V % 16:
             raise NotImplementedError("vocab_size must be a multiple of 16")
         mts = _ceil_div(max_batch, 16)
@@ -181,15 +218,6 @@ class DecodeEngine:
         auto = dtype == torch.bfloat16 and kch % 8 == 0 and 3 <= kch // 8 <= 6
         env = os.environ.get("LGEN_FUSED_NORM")
         self.fuse_norm = auto if env is None else env == "1"
-        # lgen_prefetch_hint: every kernel of the chain also touches its successor's weights (one dword per line).
-        # Measured NEGATIVE on MI355X (+106 us per decode step: the extra line requests sit in front of the
-        # kernel's own operand loads), so it is off; LGEN_PREFETCH=1 re-enables it for experiments.
-        self.prefetch = os.environ.get("LGEN_PREFETCH", "0") == "1"
-        # workgroup shapes for chains that share the chip with two or more other chains (SamplingPipeline, lanes >= 3): <= 156 VGPRs
-        # and <= 64 KB of LDS per workgroup at 256 rows, so that a workgroup fits next to another kernel's.  Measured at 128 images per
-        # chain x 3 chains (tools/exp_r3e.py): decode only 111 -> 115.7 img/s, with the decoder 100.9 -> 101.7; alone the shapes cost
-        # ~2 us per layer (w1||w3 (2, 2, 8) x 6 passes: 14.4 us against (2, 4, 8) x 3: 12.6 us)
-        self.lean = bool(getattr(model, "_lean_gemms", False)) or os.environ.get("LGEN_LEAN") == "1"
         self.tile_override = {}      # kind ("qkv" | "wo" | "w13" | "w2" | "head") -> (mt, nt, kw)
         # tuning hook: LGEN_TILES="qkv=2,4,8;wo=4,1,8;w2=4,1,8" (e.g. fewer, fatter workgroups per GEMM so that the
         # kernels of several in-flight batches share the chip side by side instead of taking turns)
@@ -201,7 +229,18 @@ class DecodeEngine:
             if len(t) != 3:
                 raise ValueError(f"LGEN_TILES: '{item}' is not kind=mt,nt,kw")
             self.tile_override[kind.strip()] = t
-        # fused-norm GEMM schedule (lgen_gemm_schedule_hint): kind -> (passes, double_buffer); LGEN_PASSES="qkv=2,1;w13=3,0"
+        # fused-norm GEMM schedule (the `passes` argument of lgen_gemm): kind -> (passes, 0); LGEN_PASSES="qkv=2,0;w13=3,0"
+        # big-M tile family (round 4): LGEN_GEMM_TILE=0 keeps the skinny kernels; LGEN_TILE_SHAPES="qkv=4,1,1,3,4,4,4;..." picks shapes
+        self.use_tile = os.environ.get("LGEN_GEMM_TILE", "1") != "0"
+        self.tile_shape_override = {}
+        for item in filter(None, os.environ.get("LGEN_TILE_SHAPES", "").split(";")):
+            kind, _, val = item.partition("=")
+            if kind.strip() not in ("qkv", "wo", "w13", "w2", "head"):
+                raise ValueError(f"LGEN_TILE_SHAPES: unknown GEMM '{kind}'")
+            t = tuple(int(v) for v in val.split(","))
+            if len(t) != 7:
+                raise ValueError(f"LGEN_TILE_SHAPES: '{item}' is not kind=wm,wn,mtv,ntv,kb,stages,lw")
+            self.tile_shape_override[kind.strip()] = t
         self.pass_override = {}
         for item in filter(None, os.environ.get("LGEN_PASSES", "").split(";")):
             kind, _, val = item.partition("=")
@@ -235,8 +274,7 @@ class DecodeEngine:
         self._graphs = {}
 
     def compatible(self, model, max_batch, S8, dtype) -> bool:
-        lean = bool(getattr(model, "_lean_gemms", False)) or os.environ.get("LGEN_LEAN") == "1"
-        return (self.B2 == max_batch and self.S8 == S8 and self.dtype == dtype and self.lean == lean
+        return (self.B2 == max_batch and self.S8 == S8 and self.dtype == dtype
                 and self.dev == model.tok_embeddings.weight.device and self._wsig == self._sig(model))
 
     def reset(self, max_batch: int):
@@ -259,9 +297,6 @@ class DecodeEngine:
         ntiles = N // 16
         kch = K // self.kc
         bf16 = self.dtype == torch.bfloat16
-        if self.lean and self.MTs >= 16 and self.fuse_norm and bf16 and kind in ("w13", "wo", "w2"):
-            return {"w13": (2, 2, 8), "wo": (2, 2, 4) if (ntiles >= 96 and kch // 4 >= 12) else (2, 1, 8),
-                    "w2": (2, 2, 4 if kch // 4 >= 12 else 8)}[kind]
         if self.MTs >= 8 and bf16 and not self.fuse_norm and kch >= 96:
             # wide models (GPT-3B: d 3200, F 8704) at 256 rows: every GEMM is the plain ring kernel and the work is MFMA-shaped
             # (64 GFLOP per layer), so big tiles and FEW K-splitting waves win -- measured (tools/gemm_sweep_wide.py,
@@ -308,6 +343,20 @@ class DecodeEngine:
         kw = max(1, min(kmax, 16 if kch >= 64 else 8, kch // 2))
         return mt, nt, kw
 
+    def _tile_shape(self, kind: str):
+        """(wm, wn, mtv, ntv, kb, stages, lw) of the big-M tile family (csrc/gemm_tile.hip) for one decode GEMM, or None where the
+        skinny kernels stay: chains of >= 256 rows, bf16, RMSNorm fused (the family's norm consumers read the producer's statistics),
+        one position for all rows.  Measured on MI355X, GPT-L, 256 rows (tools/gemm_tile_sweep.py, us per launch, skinny -> tile):
+        wqkv 10.2 -> 9.8, wo 4.85 -> 4.1, w1||w3 13.1 -> 10.6, w2 7.8 -> 7.7, lm_head 23.2 -> 20.9."""
+        if kind in self.tile_shape_override:
+            return self.tile_shape_override[kind]
+        if not self.use_tile or self.MTs < 16 or self.dtype != torch.bfloat16 or not self.fuse_norm:
+            return None
+        if kind == "qkv" and (self.pos_rows is not None or self.hd < 16):
+            return None
+        key = tile_schedule_key(self.MTs)
+        return None if key is None else TILE_SCHEDULES[key][kind]
+
     def _passes(self, kind: str, N: int, tiles):
         """(passes, double_buffer) of a fused-norm GEMM: n-groups one workgroup walks with its normalised rows kept in registers
         (gemm_normpre.hip).  One workgroup of these kernels fills a CU, so the (n-group, m-group) units are dealt out as
@@ -318,21 +367,85 @@ class DecodeEngine:
             return 1, 0
         mt, nt, _ = tiles
         units = (N // 16 // nt) * (self.MTs // max(1, math.gcd(self.MTs, mt)))
-        passes = max(1, -(-units // 256))
+        passes = min(64, max(1, -(-units // 256)))   # (the library takes 1..64: a scheduling choice only, results are identical)
         # weights of the next n-group in a second register set: no faster than reloading after the MFMAs (10.74 vs 10.76 us,
         # w1||w3 at 128 rows) and bimodal inside the decode graph (73 / 63 img/s, tools/exp_r3c.py): off
         return passes, 0
 
     # ---- launches -----------------------------------------------------------------------------
-    def gemm(self, wp, xp, out, M, mts, N, K, epi, tiles, norm_w=None, ssq_out=None, sched=None):
+    def gemm(self, wp, xp, out, M, mts, N, K, epi, tiles, norm_w=None, ssq_out=None, sched=None, tile=None):
+        if tile is not None:
+            rc = self.lib.lgen_gemm_tile(L.ptr(wp), L.ptr(xp), L.ptr(out), M, mts, N, K, epi, self.dt, *tile, L.ptr(norm_w),
+                                         L.ptr(self.ssq) if norm_w is not None else 0, self.ssq_parts, self.eps, L.ptr(ssq_out),
+                                         L.stream())
+            if rc != L.ERR_UNSUPPORTED:   # no instantiation / shape does not divide: the skinny kernel below
+                L.check(rc, "lgen_gemm_tile")
+                return
         mt, nt, kw = tiles
         if mts % mt:
             mt = math.gcd(mts, mt)
-        if sched is not None and sched[0] > 1 and norm_w is not None:
-            L.check(self.lib.lgen_gemm_schedule_hint(int(sched[0]), int(sched[1])), "lgen_gemm_schedule_hint")
+        passes = int(sched[0]) if (sched is not None and norm_w is not None) else 1
         L.check(self.lib.lgen_gemm(L.ptr(wp), L.ptr(xp), L.ptr(out), M, mts, N, K, epi, self.dt, mt, nt, kw,
                                    L.ptr(norm_w), L.ptr(self.ssq) if norm_w is not None else 0, self.ssq_parts, self.eps,
-                                   L.ptr(ssq_out), L.stream()), "lgen_gemm")
+                                   L.ptr(ssq_out), passes, L.stream()), "lgen_gemm")
+
+    def qkv_gemm(self, i, w, x_in, nw):
+        """[attention_norm +] wqkv + RoPE + KV append of layer i (gpt.py:214-226): the big-M tile form where it applies, else the
+        skinny kernels (per-row positions, narrow chains, other storage types)."""
+        lib, st, dt, M, mts = self.lib, L.stream(), self.dt, self.B2, self.MTs
+        d, H, hd, hdp, S8 = self.d, self.H, self.hd, self.hdp, self.S8
+        rows = self.pos_rows is not None
+        pos_ptr = self.pos_rows.data_ptr() if rows else self.state.data_ptr()
+        ssq = self.ssq if nw is not None else None
+        bq = self._tile_shape("qkv")
+        if bq is not None and nw is not None and not rows:
+            rc = lib.lgen_gemm_qkv_rope_tile(L.ptr(w["wqkv"]), L.ptr(x_in), L.ptr(self.qbuf), L.ptr(self.k_cache[i]),
+                                             L.ptr(self.v_cache[i]), L.ptr(self.freqs_cis), pos_ptr, M, mts, d, H, hd, hdp, S8,
+                                             self.kvs, dt, *bq, L.ptr(nw), L.ptr(ssq), self.ssq_parts, self.eps, st)
+            if rc != L.ERR_UNSUPPORTED:
+                L.check(rc, "gemm_qkv_rope_tile")
+                return
+        tq = self._tiles("qkv", 3 * d, d)
+        sq = self._passes("qkv", 3 * d, tq)
+        qkv_fn = lib.lgen_gemm_qkv_rope_rows if rows else lib.lgen_gemm_qkv_rope
+        L.check(qkv_fn(L.ptr(w["wqkv"]), L.ptr(x_in), L.ptr(self.qbuf), L.ptr(self.k_cache[i]), L.ptr(self.v_cache[i]),
+                       L.ptr(self.freqs_cis), pos_ptr, M, mts, d, H, hd, hdp, S8, self.kvs, dt, tq[0], tq[1], tq[2], L.ptr(nw),
+                       L.ptr(ssq), self.ssq_parts, self.eps, sq[0] if nw is not None else 1, st), "gemm_qkv_rope")
+
+    def gemm_kind(self, kind, w, x_in=None, nw=None):
+        """One decode GEMM of `kind` ("wo" | "w13" | "w2" | "head") on the decode workspaces with the shapes the decode graph uses
+        (also what bench.py's roofline leg and the sweep tools time)."""
+        d, F, M, mts = self.d, self.F, self.B2, self.MTs
+        fuse = self.fuse_norm
+        ssq = self.ssq if fuse else None
+        if kind == "wo":
+            self.gemm(w["wo"], self.ap, self.hp, M, mts, d, d, L.EPI_RES, self._tiles("wo", d, d), ssq_out=ssq, tile=self._tile_shape("wo"))
+        elif kind == "w13":
+            t13 = self._tiles("w13", 2 * F, d)
+            self.gemm(w["w13"], x_in if x_in is not None else self.hp, self.gp, M, mts, 2 * F, d, L.EPI_SWIGLU, t13, norm_w=nw,
+                      sched=self._passes("w13", 2 * F, t13), tile=self._tile_shape("w13") if nw is not None else None)
+        elif kind == "w2":
+            self.gemm(w["w2"], self.gp, self.hp, M, mts, d, F, L.EPI_RES, self._tiles("w2", d, F), ssq_out=ssq, tile=self._tile_shape("w2"))
+        elif kind == "head":
+            th = self._tiles("head", self.V, d)
+            self.gemm(self.out_w, x_in if x_in is not None else self.hp, self.logits, M, mts, self.V, d, L.EPI_ROWS, th, norm_w=nw,
+                      sched=self._passes("head", self.V, th), tile=self._tile_shape("head") if nw is not None else None)
+        else:
+            raise ValueError(kind)
+
+    def gemm_schedule(self) -> dict:
+        """The kernel family and shapes the decode graph launches per GEMM kind (bench.py prints it; tests pin it)."""
+        d, F = self.d, self.F
+        dims = {"wqkv": ("qkv", 3 * d, d), "wo": ("wo", d, d), "w13": ("w13", 2 * F, d), "w2": ("w2", d, F), "lm_head": ("head", self.V, d)}
+        out = {}
+        for name, (kind, N, K) in dims.items():
+            ts = self._tile_shape(kind)
+            if ts is not None and (self.fuse_norm or kind in ("wo", "w2")):
+                out[name] = {"family": "tile", "shape(wm,wn,mtv,ntv,kb,stages,lw)": list(ts)}
+            else:
+                t = self._tiles(kind, N, K)
+                out[name] = {"family": "skinny", "tile(mt,nt,kw)": list(t), "passes": self._passes(kind, N, t)[0]}
+        return out
 
     def _layers_and_logits(self, want_logits: bool = True):
         """L x [attention_norm+wqkv+rope+append | attention | wo+res | ffn_norm+w1,w3+swiglu | w2+res], then
@@ -343,18 +456,9 @@ class DecodeEngine:
         # one device scalar (generate(): all rows at the same position) or one position per row (serve.py)
         rows = self.pos_rows is not None
         pos_ptr = self.pos_rows.data_ptr() if rows else self.state.data_ptr()
-        qkv_fn = lib.lgen_gemm_qkv_rope_rows if rows else lib.lgen_gemm_qkv_rope
         attn_fn = lib.lgen_attn_decode_rows if rows else lib.lgen_attn_decode
         fuse = self.fuse_norm
-        tq, to, t13, t2, th = (self._tiles("qkv", 3 * d, d), self._tiles("wo", d, d), self._tiles("w13", 2 * F, d),
-                               self._tiles("w2", d, F), self._tiles("head", self.V, d))
         pm = self._mask()
-        ssq = self.ssq if fuse else None
-        sq, s13, sh = self._passes("qkv", 3 * d, tq), self._passes("w13", 2 * F, t13), self._passes("head", self.V, th)
-
-        def hint(t):
-            if self.prefetch:
-                lib.lgen_prefetch_hint(L.ptr(t), t.numel() * t.element_size())
 
         nlayers = len(self.layers)
         for i, w in enumerate(self.layers):
@@ -363,41 +467,32 @@ class DecodeEngine:
             else:
                 L.check(lib.lgen_rmsnorm(L.ptr(self.hp), L.ptr(w["an"]), L.ptr(self.xnp), mts, d, self.eps, dt, st), "rmsnorm")
                 x_in, nw = self.xnp, None
-            if fuse and sq[0] > 1:
-                L.check(lib.lgen_gemm_schedule_hint(sq[0], sq[1]), "lgen_gemm_schedule_hint")
-            L.check(qkv_fn(L.ptr(w["wqkv"]), L.ptr(x_in), L.ptr(self.qbuf), L.ptr(self.k_cache[i]),
-                           L.ptr(self.v_cache[i]), L.ptr(self.freqs_cis), pos_ptr, M, mts, d, H, hd, hdp,
-                           S8, self.kvs, dt, tq[0], tq[1], tq[2], L.ptr(nw), L.ptr(ssq), self.ssq_parts, self.eps, st),
-                    "gemm_qkv_rope")
+            self.qkv_gemm(i, w, x_in, nw)
             if self._prof is not None:  # bench.py roofline leg: HIP events on the launch stream
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            hint(w["wo"])
             L.check(attn_fn(L.ptr(self.qbuf), L.ptr(self.k_cache[i]), L.ptr(self.v_cache[i]), L.ptr(self.ap),
-                            pos_ptr, L.ptr(pm), self.T if pm is not None else 0, M, mts, H, hd, hdp, S8, self.kvs, dt, st), "attn_decode")
+                            pos_ptr, L.ptr(pm), self.T if pm is not None else 0, M, mts, H, hd, hdp, S8, self.kvs, dt, self.attn_variant, st),
+                    "attn_decode")
             if self._prof is not None:
                 e1.record()
                 self._prof["events"].append((e0, e1))
-            hint(w["w13"])
-            self.gemm(w["wo"], self.ap, self.hp, M, mts, d, d, L.EPI_RES, to, ssq_out=ssq)
+            self.gemm_kind("wo", w)
             self.ssq_parts = d // 16
             if fuse:
                 x_in, nw = self.hp, w["fn"]
             else:
                 L.check(lib.lgen_rmsnorm(L.ptr(self.hp), L.ptr(w["fn"]), L.ptr(self.xnp), mts, d, self.eps, dt, st), "rmsnorm")
                 x_in, nw = self.xnp, None
-            hint(w["w2"])
-            self.gemm(w["w13"], x_in, self.gp, M, mts, 2 * F, d, L.EPI_SWIGLU, t13, norm_w=nw, sched=s13)
-            hint(self.layers[i + 1]["wqkv"] if i + 1 < nlayers else self.out_w)
-            self.gemm(w["w2"], self.gp, self.hp, M, mts, d, F, L.EPI_RES, t2, ssq_out=ssq)
+            self.gemm_kind("w13", w, x_in, nw)
+            self.gemm_kind("w2", w)
         if want_logits:
             if fuse:
                 x_in, nw = self.hp, self.norm_w
             else:
                 L.check(lib.lgen_rmsnorm(L.ptr(self.hp), L.ptr(self.norm_w), L.ptr(self.xnp), mts, d, self.eps, dt, st), "rmsnorm")
-                x_in, nw = self.xnp, None
-            hint(self.layers[0]["wqkv"])  # the next decode step starts there
-            self.gemm(self.out_w, x_in, self.logits, M, mts, self.V, d, L.EPI_ROWS, th, norm_w=nw, sched=sh)
+                x_in, nw = self.xnp, None  # the next decode step starts there
+            self.gemm_kind("head", None, x_in, nw)
 
     def launches_per_step(self) -> int:
         """Kernel launches of one captured decode step (embed + L layers + norm/lm_head + sampler)."""
@@ -611,7 +706,8 @@ class DecodeEngine:
         self._sample(B, sp)
         yield 0
         # ---- decode (generate.py:105-123): every step first advances (pos, step)
-        key = (B, N, self._mask() is not None, self.fuse_norm, tuple(sorted(self.tile_override.items())),
+        key = (B, N, self._mask() is not None, self.fuse_norm, self.use_tile, tuple(sorted(self.tile_shape_override.items())),
+               tuple(sorted(self.tile_override.items())),
                tuple(sorted(self.pass_override.items())), sp["use_cfg"], sp["cfg_scale"],
                sp["cfg_interval"], sp["temperature"], sp["top_k"], sp["top_p"], sp["sample_logits"],
                self.noise.data_ptr() if sampling else 0)

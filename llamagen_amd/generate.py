@@ -23,6 +23,15 @@ def generate(model, cond, max_new_tokens, emb_masks=None, cfg_scale=1.0, cfg_int
             return stop.value
 
 
+class PadBatch:
+    """Filler batch of a decode chain (llamagen_amd/pipeline.py: a last, incomplete chain keeps the lane's chain shape).  Its rows
+    are computed and dropped; it draws NO noise, so the device generator ends up where consecutive reference generate() calls
+    would leave it."""
+
+    def __init__(self, value):
+        self.value = value   # (cond, emb_masks or None): any valid conditioning, e.g. the chain's first batch
+
+
 def _null_condition(model, cond):
     """The unconditional twin of every row of `cond` (reference generate.py:128-141): class-conditional models reserve class id
     `num_classes` for "no class"; text-conditional models carry a learned [T, C] null caption."""
@@ -62,14 +71,15 @@ def generate_iter(model, cond, max_new_tokens, emb_masks=None, cfg_scale=1.0, cf
                            dtype=model.tok_embeddings.weight.dtype)
         parts, mask_parts = [cond], [emb_masks]
         for j in range(groups):
+            pad = j > 0 and isinstance(more_conds[j - 1], PadBatch)
             if j > 0:
-                item = more_conds[j - 1]() if callable(more_conds[j - 1]) else more_conds[j - 1]
+                item = more_conds[j - 1].value if pad else (more_conds[j - 1]() if callable(more_conds[j - 1]) else more_conds[j - 1])
                 c_j, m_j = item if isinstance(item, tuple) else (item, None)   # text-conditional: (caption_embs, emb_masks)
                 if c_j.shape != cond.shape:
                     raise ValueError("batches that share a chain must have the same size")
                 parts.append(c_j)
                 mask_parts.append(m_j if m_j is not None else emb_masks)        # no own mask: the shared one (or none at all)
-            if sample_logits:
+            if sample_logits and not pad:   # (a filler's slice of the noise buffer keeps whatever it held: finite, unused)
                 model._engine.draw_noise(max_new_tokens, n * groups, j * n, n)
         cond = torch.cat(parts)
         if any(m is not None for m in mask_parts):

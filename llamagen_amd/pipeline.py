@@ -17,13 +17,11 @@ the default generator batch by batch in submission order, exactly as consecutive
 """
 from __future__ import annotations
 
-import ctypes
-import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
 
-from .generate import generate_iter
+from .generate import PadBatch, generate_iter
 
 
 def _eval_batch(c):
@@ -31,28 +29,6 @@ def _eval_batch(c):
     returns either (evaluated only when its chain starts: RNG order) -> (cond, emb_masks or None)."""
     c = c() if callable(c) else c
     return c if isinstance(c, tuple) else (c, None)
-
-
-def cu_mask_words(n_cu: int, part: int, parts: int) -> List[int]:
-    """32-bit mask words selecting the `part`-th of `parts` contiguous slices of CU bits 0..n_cu-1.  On multi-XCD
-    parts the kernel driver is understood to deal consecutive mask bits round-robin over the XCDs, in which case a
-    contiguous bit range is an (almost) equal share of every XCD -- each lane keeps all eight L2s and one eighth of
-    its CUs behind each (the bit-to-XCD mapping itself has not been measured here)."""
-    lo, hi = part * n_cu // parts, (part + 1) * n_cu // parts
-    words = [0] * ((n_cu + 31) // 32)
-    for b in range(lo, hi):
-        words[b // 32] |= 1 << (b % 32)
-    return words
-
-
-def masked_stream(dev: torch.device, words: Sequence[int]):
-    """A torch handle on a HIP stream restricted to the CUs of `words` (lgen_stream_create_cu_mask)."""
-    from . import _lib as L
-    arr = (ctypes.c_uint32 * len(words))(*words)
-    out = ctypes.c_void_p()
-    with torch.cuda.device(dev):
-        L.check(L.lib().lgen_stream_create_cu_mask(arr, len(words), ctypes.byref(out)), "lgen_stream_create_cu_mask")
-    return torch.cuda.ExternalStream(out.value, device=dev)
 
 
 class SamplingLane:
@@ -120,7 +96,6 @@ class SamplingPipeline:
     results are enqueued-behind on the CURRENT stream when run() returns (no host synchronisation)."""
 
     def __init__(self, gpt, vq=None, lanes: int = 2, steps_per_turn: int = 1, vq_low_priority: bool = False,
-                 cu_partition: Optional[bool] = None, vq_cus: int = 0, lanes_avoid_vq_cus: bool = False,
                  batches_per_chain: int = 1, vq_chunk: int = 0):
         self.dev = next(gpt.parameters()).device
         # `batches_per_chain` consecutive batches of run() share ONE decode chain (their rows are concatenated): rows never
@@ -132,43 +107,11 @@ class SamplingPipeline:
         # (text-conditional batches may be given as (caption_embs, emb_masks) tuples: a chain concatenates both)
         # optional: one shared stream for every lane's VQ decode (see SamplingLane)
         self.vq_stream = torch.cuda.Stream(device=self.dev, priority=0) if (vq is not None and vq_low_priority) else None
-        # experiment (bench.py --vq-cus N): the MFMA-bound decoder kernels fill the register file of every CU they run on
-        # (2 x 256 threads x 186 VGPRs), so nothing of the decode lanes co-resides with them; confining the decoder to N
-        # CUs (one shared, CU-masked stream) leaves the other CUs to the latency-bound decode chains
-        n_cu = torch.cuda.get_device_properties(self.dev).multi_processor_count if torch.cuda.is_available() else 256
-        if vq_cus < 0 or vq_cus >= n_cu:
-            raise ValueError(f"vq_cus must satisfy 0 <= vq_cus < {n_cu} (an all-zero CU mask cannot run anything)")
-        if lanes_avoid_vq_cus and vq_cus == 0:
-            raise ValueError("lanes_avoid_vq_cus needs vq_cus > 0")
-        if lanes_avoid_vq_cus and (cu_partition or os.environ.get("LGEN_LANE_CU_MASK", "0") == "1"):
-            raise ValueError("lanes_avoid_vq_cus and cu_partition both define the lanes' CU masks: use one of them")
-        if vq is not None and vq_cus > 0:
-            words = [0] * ((n_cu + 31) // 32)
-            for b in range(min(vq_cus, n_cu)):
-                words[b // 32] |= 1 << (b % 32)
-            self.vq_stream = masked_stream(self.dev, words)
         lanes = max(1, lanes)
-        # optional (experiment, LGEN_LANE_CU_MASK=1): every lane's stream owns 1/lanes of the CUs, so that the lanes'
-        # kernels run side by side on disjoint CUs instead of each launch spreading over the whole chip.  Measured
-        # SLOWER on MI355X (tools/quick_cu_mask.py, decode only, 3 lanes: 69 vs 91 img/s sharing the whole chip;
-        # identical tokens), so it stays off
-        if cu_partition is None:
-            cu_partition = os.environ.get("LGEN_LANE_CU_MASK", "0") == "1"
-        streams = [None] * lanes
-        if lanes_avoid_vq_cus and vq_cus > 0:
-            words = [0] * ((n_cu + 31) // 32)
-            for b in range(vq_cus, n_cu):
-                words[b // 32] |= 1 << (b % 32)
-            streams = [masked_stream(self.dev, words) for _ in range(lanes)]
-        if cu_partition and lanes > 1:
-            streams = [masked_stream(self.dev, cu_mask_words(n_cu, i, lanes)) for i in range(lanes)]
-        self.cu_partition = bool(cu_partition and lanes > 1)
-        self.lanes: List[SamplingLane] = [SamplingLane(gpt, vq, stream=streams[i], primary=(i == 0), vq_stream=self.vq_stream,
+        # (CU-masked lane streams and a CU-confined decoder stream were measured slower in rounds 1-3 -- 69 vs 91 img/s, 45-59 vs 76 --
+        # and removed in round 4: profiles/HISTORY.md)
+        self.lanes: List[SamplingLane] = [SamplingLane(gpt, vq, stream=None, primary=(i == 0), vq_stream=self.vq_stream,
                                                        vq_chunk=vq_chunk) for i in range(lanes)]
-        # three or more chains in flight: the engines pick GEMM workgroup shapes with a smaller register / LDS footprint (they
-        # co-reside with the other chains' kernels; engine.DecodeEngine.lean), a little slower alone, faster together
-        for lane in self.lanes:
-            lane.gpt._lean_gemms = lanes >= 3
         self.steps_per_turn = steps_per_turn
 
     def prepare(self, batch: int, max_new_tokens: int, **gen_kw):
@@ -180,9 +123,9 @@ class SamplingPipeline:
         for _ in self.lanes:
             if gpt.model_type == "c2i":
                 conds += [torch.randint(0, max(1, gpt.num_classes), (batch,), generator=g).to(self.dev) for _ in range(self.bpc)]
-            else:
-                conds.append(torch.zeros(batch, gpt.cls_token_num, gpt.config.caption_dim, device=self.dev,
-                                         dtype=gpt.tok_embeddings.weight.dtype))
+            else:   # one whole chain per lane here too: every lane allocates its slabs and captures its graph now, not in a timed run
+                conds += [torch.zeros(batch, gpt.cls_token_num, gpt.config.caption_dim, device=self.dev,
+                                      dtype=gpt.tok_embeddings.weight.dtype) for _ in range(self.bpc)]
         self.run(conds, max_new_tokens, **gen_kw)
         torch.cuda.synchronize(self.dev)
 
@@ -210,10 +153,12 @@ class SamplingPipeline:
                         # the chain's first batch now; the others are evaluated by generate_iter in RNG order (labels of batch j,
                         # noise of batch j, labels of batch j + 1, ...).  A last, incomplete group repeats its last batch (rows
                         # computed and dropped): one chain shape per lane
-                        pad = group[-1] if not callable(group[-1]) else (lambda c=(chain, mask0): c)
+                        # (PadBatch: rows computed and dropped, NO Exp(1) draws -- the default generator is left exactly where
+                        # the reference's consecutive generate() calls would leave it)
+                        pad = PadBatch((chain, mask0))
                         more = group[1:] + [pad] * (self.bpc - len(group))
                         if "_noise_seq" in gen_kw:  # injected noise (tests): evaluate now, the whole chain's block is given
-                            parts = [(chain, mask0)] + [ev(c) for c in more]
+                            parts = [(chain, mask0)] + [c.value if isinstance(c, PadBatch) else ev(c) for c in more]
                             if any(c.shape[0] != rows for c, _ in parts):
                                 raise ValueError("batches that share a chain must have the same size")
                             chain = torch.cat([c for c, _ in parts])

@@ -67,12 +67,12 @@ class _Act:
 class VQEngine:
     def __init__(self, model):
         self.lib = L.lib()
-        if os.environ.get("LGEN_VQ_NT") is not None:  # tuning knob, see lgen_set_vq_nt in lgen.h
-            self.lib.lgen_set_vq_nt(int(os.environ["LGEN_VQ_NT"]))
+        if os.environ.get("LGEN_VQ_NT") is not None:  # tuning knob, see lgen_debug_set_vq_nt in lgen.h
+            self.lib.lgen_debug_set_vq_nt(int(os.environ["LGEN_VQ_NT"]))
         self.dev = model.post_quant_conv.weight.device
         self.fused = os.environ.get("LGEN_VQ_FUSED", "1") != "0"  # lgen_conv_fused where the shape allows it
-        if os.environ.get("LGEN_CF_VARIANT") is not None:  # tuning knob, see lgen_set_conv_fused_variant in lgen.h
-            self.lib.lgen_set_conv_fused_variant(int(os.environ["LGEN_CF_VARIANT"]))
+        if os.environ.get("LGEN_CF_VARIANT") is not None:  # tuning knob, see lgen_debug_set_conv_fused_variant in lgen.h
+            self.lib.lgen_debug_set_conv_fused_variant(int(os.environ["LGEN_CF_VARIANT"]))
         cfg = model.config
         self.n_e, self.e_dim, self.l2 = cfg.codebook_size, cfg.codebook_embed_dim, cfg.codebook_l2_norm
         self._sig_v = self._sig(model)

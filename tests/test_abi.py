@@ -32,7 +32,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/ but not exported"
         assert s in _lib.SIGNATURES, f"{s} has no ctypes signature"
-    assert lib.lgen_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.lgen_abi_version() == _lib.ABI_VERSION == 7
 
 
 def test_header_arg_counts_match_ctypes_signatures():
@@ -120,24 +120,21 @@ def test_tile_heuristics_are_valid_for_every_registry_model(lib):
                 kch = d // kc
                 for fuse in (False, True):
                     fuse = fuse and dtype == L.BF16 and kch % 8 == 0 and 3 <= kch // 8 <= 6
-                    for lean in (False, True):   # lean: the shapes SamplingPipeline asks for with >= 3 chains in flight
-                        eng = types.SimpleNamespace(tile_override={}, pass_override={}, fuse_norm=fuse, mt=min(mts, 4), MTs=mts, kc=kc,
-                                                    lib=lib, lean=lean, dtype=torch.bfloat16 if dtype == L.BF16 else torch.float32)
-                        for kind, N, K, epi in (("qkv", 3 * d, d, None), ("wo", d, d, L.EPI_RES), ("w13", 2 * F, d, L.EPI_SWIGLU),
-                                                ("w2", d, F, L.EPI_RES), ("head", 16384, d, L.EPI_ROWS)):
-                            mt, nt, kw = DecodeEngine._tiles(eng, kind, N, K)
-                            nw = 8 if (fuse and kind in ("qkv", "w13", "head")) else 0
-                            passes, db = DecodeEngine._passes(eng, kind, N, (mt, nt, kw))   # round 3: n-groups per workgroup
-                            assert passes >= 1 and (passes == 1 or nw), (kind, passes)
-                            if passes > 1:
-                                assert lib.lgen_gemm_schedule_hint(passes, db) == 0
-                            if kind == "qkv":
-                                rc = lib.lgen_gemm_qkv_rope(8, 8, 8, 8, 8, 8, 8, B2, mts, d, H, d // H, 64 if d // H <= 64 else 128, 584, 0,
-                                                            dtype, mt, nt, kw, nw, 8 if nw else 0, kch, 1e-5, 0)
-                            else:
-                                rc = lib.lgen_gemm(8, 8, 8, B2, mts, N, K, epi, dtype, mt, nt, kw, nw, 8 if nw else 0, kch, 1e-5, 0, 0)
-                            if rc in (-1, -2):
-                                bad.append((name, dtype, B2, fuse, lean, kind, (mt, nt, kw), rc))
+                    eng = types.SimpleNamespace(tile_override={}, pass_override={}, fuse_norm=fuse, mt=min(mts, 4), MTs=mts, kc=kc,
+                                                lib=lib, dtype=torch.bfloat16 if dtype == L.BF16 else torch.float32)
+                    for kind, N, K, epi in (("qkv", 3 * d, d, None), ("wo", d, d, L.EPI_RES), ("w13", 2 * F, d, L.EPI_SWIGLU),
+                                            ("w2", d, F, L.EPI_RES), ("head", 16384, d, L.EPI_ROWS)):
+                        mt, nt, kw = DecodeEngine._tiles(eng, kind, N, K)
+                        nw = 8 if (fuse and kind in ("qkv", "w13", "head")) else 0
+                        passes, _ = DecodeEngine._passes(eng, kind, N, (mt, nt, kw))   # n-groups per workgroup (explicit argument, ABI v7)
+                        assert 1 <= passes <= 64 and (passes == 1 or nw), (kind, passes)
+                        if kind == "qkv":
+                            rc = lib.lgen_gemm_qkv_rope(8, 8, 8, 8, 8, 8, 8, B2, mts, d, H, d // H, 64 if d // H <= 64 else 128, 584, 0,
+                                                        dtype, mt, nt, kw, nw, 8 if nw else 0, kch, 1e-5, passes, 0)
+                        else:
+                            rc = lib.lgen_gemm(8, 8, 8, B2, mts, N, K, epi, dtype, mt, nt, kw, nw, 8 if nw else 0, kch, 1e-5, 0, passes, 0)
+                        if rc in (-1, -2):
+                            bad.append((name, dtype, B2, fuse, kind, (mt, nt, kw), rc))
     assert not bad, bad[:10]
 
 
@@ -147,9 +144,9 @@ def test_measured_tile_tables_of_round_3(lib):
     import types
     from llamagen_amd.engine import DecodeEngine
 
-    def tiles(d, F, mts, fuse, lean=False):
+    def tiles(d, F, mts, fuse):
         eng = types.SimpleNamespace(tile_override={}, pass_override={}, fuse_norm=fuse, mt=min(mts, 4), MTs=mts, kc=32, lib=lib,
-                                    lean=lean, dtype=torch.bfloat16)
+                                    dtype=torch.bfloat16)
         return {k: DecodeEngine._tiles(eng, k, n, kk) for k, n, kk in (("qkv", 3 * d, d), ("wo", d, d), ("w13", 2 * F, d),
                                                                       ("w2", d, F), ("head", 16384, d))}
     assert tiles(3200, 8704, 16, False) == {"qkv": (4, 4, 4), "wo": (4, 4, 4), "w13": (8, 2, 4), "w2": (4, 4, 8), "head": (8, 2, 4)}
@@ -158,9 +155,8 @@ def test_measured_tile_tables_of_round_3(lib):
     assert small["w13"][0] <= 4 and small["qkv"][2] == 8
     gl = tiles(1024, 2816, 16, True)                                      # GPT-L, 256 rows
     assert gl["w2"] == (2, 2, 4) and gl["wo"] == (4, 1, 8) and gl["qkv"] == (1, 4, 8) and gl["w13"] == (2, 4, 8)
-    assert tiles(1024, 2816, 16, True, lean=True)["w2"] == (2, 2, 4) and tiles(1024, 2816, 16, True, lean=True)["wo"] == (2, 1, 8)
     gx = tiles(1536, 4096, 16, True)                                      # GPT-XXL: wo has 96 n-tiles and 12 chunks per wave at kw 4
-    assert gx["wo"] == (2, 2, 4) and gx["w2"] == (2, 2, 4) and tiles(1536, 4096, 16, True, lean=True)["wo"] == (2, 2, 4)
+    assert gx["wo"] == (2, 2, 4) and gx["w2"] == (2, 2, 4)
     assert tiles(1024, 2816, 8, True)["w2"] != (2, 2, 4)                  # 128 rows keep the round-2 shapes
 
 
@@ -194,22 +190,6 @@ def test_hot_kernels_have_no_register_spills():
         members = [n for n in kernels if family in n]
         assert members, family
         assert all(kernels[n].get("ScratchSize", 0) == 0 for n in members), family
-
-
-def test_lane_cu_masks_partition_the_chip():
-    """pipeline.cu_mask_words: the lanes' CU masks are disjoint, cover every CU, and differ by at most one CU."""
-    from llamagen_amd.pipeline import cu_mask_words
-    for n_cu in (256, 304, 64):
-        for parts in (1, 2, 3, 4):
-            masks = [cu_mask_words(n_cu, i, parts) for i in range(parts)]
-            bits = [sum(bin(w).count("1") for w in m) for m in masks]
-            assert sum(bits) == n_cu and max(bits) - min(bits) <= 1
-            for w in range(len(masks[0])):
-                acc = 0
-                for m in masks:
-                    assert acc & m[w] == 0
-                    acc |= m[w]
-            assert all(0 <= w < 2 ** 32 for m in masks for w in m)
 
 
 def test_graft_entry_build_passes():

@@ -106,18 +106,18 @@ def test_gemm_rows_packed_res(dt, M, N, K, tiles):
     xp, wp = pack_act(x.to(dev), mts), pack_weight(w.to(dev))
     ref = O.linear(x.float(), w.float(), dt)
     rows = torch.zeros(mts * 16, N, dtype=dt, device=dev)
-    L.check(L.lib().lgen_gemm(L.ptr(wp), L.ptr(xp), L.ptr(rows), M, mts, N, K, L.EPI_ROWS, code, mt, nt, kw, 0, 0, 0, 0.0, 0, L.stream()), "gemm rows")
+    L.check(L.lib().lgen_gemm(L.ptr(wp), L.ptr(xp), L.ptr(rows), M, mts, N, K, L.EPI_ROWS, code, mt, nt, kw, 0, 0, 0, 0.0, 0, 1, L.stream()), "gemm rows")
     _close(rows[:M], ref, dt, "gemm rows")
     kc = _kc(dt)
     if N % kc == 0:
         pk = torch.zeros(N // kc, mts, 64, kc // 4, dtype=dt, device=dev)
-        L.check(L.lib().lgen_gemm(L.ptr(wp), L.ptr(xp), L.ptr(pk), M, mts, N, K, L.EPI_PACKED, code, mt, nt, kw, 0, 0, 0, 0.0, 0, L.stream()), "gemm packed")
+        L.check(L.lib().lgen_gemm(L.ptr(wp), L.ptr(xp), L.ptr(pk), M, mts, N, K, L.EPI_PACKED, code, mt, nt, kw, 0, 0, 0, 0.0, 0, 1, L.stream()), "gemm packed")
         _close(unpack_act(pk, M), ref, dt, "gemm packed")
         h0 = _rand((M, N), dt, 5)
         hp = pack_act(h0.to(dev), mts)
-        L.check(L.lib().lgen_gemm(L.ptr(wp), L.ptr(xp), L.ptr(hp), M, mts, N, K, L.EPI_RES, code, mt, nt, kw, 0, 0, 0, 0.0, 0, L.stream()), "gemm res")
+        L.check(L.lib().lgen_gemm(L.ptr(wp), L.ptr(xp), L.ptr(hp), M, mts, N, K, L.EPI_RES, code, mt, nt, kw, 0, 0, 0, 0.0, 0, 1, L.stream()), "gemm res")
         _close(unpack_act(hp, M), O._rnd(h0.float() + ref, dt), dt, "gemm res", mag=ref)
-        L.check(L.lib().lgen_gemm(L.ptr(wp), L.ptr(xp), L.ptr(pk), M, mts, N, K, L.EPI_GELU, code, mt, nt, kw, 0, 0, 0, 0.0, 0, L.stream()), "gemm gelu")
+        L.check(L.lib().lgen_gemm(L.ptr(wp), L.ptr(xp), L.ptr(pk), M, mts, N, K, L.EPI_GELU, code, mt, nt, kw, 0, 0, 0, 0.0, 0, 1, L.stream()), "gemm gelu")
         _close(unpack_act(pk, M), O._rnd(O.gelu_tanh(ref), dt), dt, "gemm gelu", frac_ulp1=0.05, mag=ref)  # |gelu'| <= 1.13: a flip of the input carries over
 
 
@@ -136,7 +136,7 @@ def test_gemm_swiglu(dt, M, F, K, tiles):
     out = torch.zeros(F // kc, mts, 64, kc // 4, dtype=dt, device=dev)
     xp = pack_act(x.to(dev), mts)
     L.check(L.lib().lgen_gemm(L.ptr(w13), L.ptr(xp), L.ptr(out), M, mts, 2 * F, K, L.EPI_SWIGLU,
-                              code, mt, nt, kw, 0, 0, 0, 0.0, 0, L.stream()), "gemm swiglu")
+                              code, mt, nt, kw, 0, 0, 0, 0.0, 0, 1, L.stream()), "gemm swiglu")
     a1, a3 = O.linear(x.float(), w1.float(), dt), O.linear(x.float(), w3.float(), dt)
     ref = O._rnd(O._rnd(torch.nn.functional.silu(a1), dt) * a3, dt)
     _close(unpack_act(out, M), ref, dt, "swiglu", frac_ulp1=0.05, ulps=3)  # product of two independently flipping factors
@@ -162,14 +162,14 @@ def test_gemm_steady_state_form_is_bit_identical(M, N, K, tiles, monkeypatch):
 
     def run():
         rows = torch.zeros(mts * 16, N, dtype=dt, device=dev)
-        L.check(L.lib().lgen_gemm(L.ptr(wp), L.ptr(xp), L.ptr(rows), M, mts, N, K, L.EPI_ROWS, code, mt, nt, kw, 0, 0, 0, 0.0, 0, L.stream()), "rows")
+        L.check(L.lib().lgen_gemm(L.ptr(wp), L.ptr(xp), L.ptr(rows), M, mts, N, K, L.EPI_ROWS, code, mt, nt, kw, 0, 0, 0, 0.0, 0, 1, L.stream()), "rows")
         hp = pack_act(h0.to(dev), mts)
         ssq = torch.zeros(mts * 16 * 256, dtype=torch.float32, device=dev)
-        L.check(L.lib().lgen_gemm(L.ptr(wp), L.ptr(xp), L.ptr(hp), M, mts, N, K, L.EPI_RES, code, mt, nt, kw, 0, 0, 0, 0.0, L.ptr(ssq), L.stream()), "res")
+        L.check(L.lib().lgen_gemm(L.ptr(wp), L.ptr(xp), L.ptr(hp), M, mts, N, K, L.EPI_RES, code, mt, nt, kw, 0, 0, 0, 0.0, L.ptr(ssq), 1, L.stream()), "res")
         out = [rows, hp, ssq]
         if nt % 2 == 0:
             g = torch.zeros(N // 2 // 32, mts, 64, 8, dtype=dt, device=dev)
-            L.check(L.lib().lgen_gemm(L.ptr(w13), L.ptr(xp), L.ptr(g), M, mts, N, K, L.EPI_SWIGLU, code, mt, nt, kw, 0, 0, 0, 0.0, 0, L.stream()), "swiglu")
+            L.check(L.lib().lgen_gemm(L.ptr(w13), L.ptr(xp), L.ptr(g), M, mts, N, K, L.EPI_SWIGLU, code, mt, nt, kw, 0, 0, 0, 0.0, 0, 1, L.stream()), "swiglu")
             out.append(g)
         torch.cuda.synchronize()
         return out
@@ -212,7 +212,7 @@ def test_fused_rmsnorm_chain(dt, M, d, F, tiles):
     wop, nw_d = pack_weight(wo.to(dev)), nw.to(dev)
     # 1. producer: h = h0 + wo(a), ssq partials per 16-column tile
     L.check(lib.lgen_gemm(L.ptr(wop), L.ptr(ap), L.ptr(hp), M, mts, d, d, L.EPI_RES, code, mt, nt, kw, 0, 0, 0, 0.0,
-                          L.ptr(ssq), L.stream()), "res+ssq")
+                          L.ptr(ssq), 1, L.stream()), "res+ssq")
     h_ref = O._rnd(h0.float() + O.linear(a_in.float(), wo.float(), dt), dt)
     h_got = unpack_act(hp, M).float().cpu()
     _close(h_got, h_ref, dt, "res", mag=O.linear(a_in.float(), wo.float(), dt))
@@ -225,22 +225,22 @@ def test_fused_rmsnorm_chain(dt, M, d, F, tiles):
     mt_n = min(mt, 4)  # fused-norm GEMMs exist up to 4 m-tiles per workgroup (mt = 8 would spill: refused by the library)
     if mt == 8:
         assert lib.lgen_gemm(L.ptr(w13), L.ptr(hp), L.ptr(gp), M, mts, 2 * F, d, L.EPI_SWIGLU, code, 8, 2, kw, L.ptr(nw_d),
-                             L.ptr(ssq), d // 16, 1e-5, 0, L.stream()) == L.ERR_UNSUPPORTED
+                             L.ptr(ssq), d // 16, 1e-5, 0, 1, L.stream()) == L.ERR_UNSUPPORTED
     L.check(lib.lgen_gemm(L.ptr(w13), L.ptr(hp), L.ptr(gp), M, mts, 2 * F, d, L.EPI_SWIGLU, code, mt_n, 2, kw, L.ptr(nw_d),
-                          L.ptr(ssq), d // 16, 1e-5, 0, L.stream()), "norm+swiglu")
+                          L.ptr(ssq), d // 16, 1e-5, 0, 1, L.stream()), "norm+swiglu")
     a1, a3 = O.linear(xn_ref, w1.float(), dt), O.linear(xn_ref, w3.float(), dt)
     _close(unpack_act(gp, M), O._rnd(O._rnd(torch.nn.functional.silu(a1), dt) * a3, dt), dt, "norm+swiglu", frac_ulp1=0.08, ulps=3)
     rows = torch.zeros(R, 256, dtype=dt, device=dev)
     woutp = pack_weight(wout.to(dev))
     L.check(lib.lgen_gemm(L.ptr(woutp), L.ptr(hp), L.ptr(rows), M, mts, 256, d, L.EPI_ROWS, code, mt_n, nt, kw, L.ptr(nw_d),
-                          L.ptr(ssq), d // 16, 1e-5, 0, L.stream()), "norm+rows")
+                          L.ptr(ssq), d // 16, 1e-5, 0, 1, L.stream()), "norm+rows")
     _close(rows[:M], O.linear(xn_ref, wout.float(), dt), dt, "norm+rows", frac_ulp1=0.05)
     # 3. ssq_pack / embed produce the same statistic (their own d/16 partials)
     ssq2 = torch.full((R, L.SSQ_STRIDE), float("nan"), device=dev)
     L.check(lib.lgen_ssq_pack(L.ptr(hp), L.ptr(ssq2), mts, d, code, L.stream()), "ssq_pack")
     np.testing.assert_allclose(ssq2[:M, :d // 16].sum(1).cpu().numpy(), (h_got.double() ** 2).sum(-1).float().numpy(), rtol=1e-5)
     L.check(lib.lgen_gemm(L.ptr(woutp), L.ptr(hp), L.ptr(rows), M, mts, 256, d, L.EPI_ROWS, code, mt_n, nt, kw, L.ptr(nw_d),
-                          L.ptr(ssq2), d // 16, 1e-5, 0, L.stream()), "norm+rows (ssq_pack parts)")
+                          L.ptr(ssq2), d // 16, 1e-5, 0, 1, L.stream()), "norm+rows (ssq_pack parts)")
     _close(rows[:M], O.linear(xn_ref, wout.float(), dt), dt, "norm+rows 2", frac_ulp1=0.05)
     table = _rand((50, d), dt, 38)
     idx = torch.randint(0, 50, (M,), generator=torch.Generator().manual_seed(39)).to(torch.int32)
@@ -254,47 +254,10 @@ def test_fused_rmsnorm_chain(dt, M, d, F, tiles):
     np.testing.assert_allclose(ssq2[:M, :d // 16].sum(1).cpu().numpy(), (e_ref.double() ** 2).sum(-1).float().numpy(), rtol=1e-5)
 
 
-@pytest.mark.skipif(os.environ.get("LGEN_EXPERIMENTAL") != "1", reason="round-4 experiment hook (LGEN_EXPERIMENTAL=1): the RMSNorm-prologue "
-                    "variant of the steady-state ring kernel is compiled and ISA-checked but was never run on a GPU in round 3")
-@pytest.mark.parametrize("M,d,F,tiles", [(256, 1024, 2816, (4, 4, 4)), (256, 1024, 2816, (2, 4, 4)), (128, 1536, 4096, (4, 2, 4))])
-def test_gemm_steady_state_norm_prologue_is_bit_identical(M, d, F, tiles, monkeypatch):
-    """LGEN_GEMM_STEADY_NORM=1: fused-norm GEMMs with kw = 4 (the register-resident form needs 8 waves) run the steady-state ring
-    kernel with the RMSNorm prologue; same statistics, wave partition and chunk order as the generic prologue kernel -> identical bits."""
-    from llamagen_amd.engine import pack_act, pack_weight
-    L, dev = _L(), _dev()
-    lib, dt, code = L.lib(), torch.bfloat16, _code(torch.bfloat16)
-    mts = (M + 15) // 16
-    mt, nt, kw = tiles
-    h = _rand((M, d), dt, 41)
-    nw = (1 + 0.1 * _rand((d,), torch.float32, 42)).to(dt).to(dev)
-    w1, w3, wout = _rand((F, d), dt, 43, 0.05), _rand((F, d), dt, 44, 0.05), _rand((512, d), dt, 45, 0.05)
-    hp = pack_act(h.to(dev), mts)
-    ssq = torch.zeros(mts * 16, L.SSQ_STRIDE, device=dev)
-    L.check(lib.lgen_ssq_pack(L.ptr(hp), L.ptr(ssq), mts, d, code, L.stream()), "ssq_pack")
-    w13 = torch.stack([pack_weight(w1.to(dev)), pack_weight(w3.to(dev))], dim=1).flatten(0, 1).contiguous()
-    woutp = pack_weight(wout.to(dev))
-
-    def run():
-        gp = torch.zeros(F // 32, mts, 64, 8, dtype=dt, device=dev)
-        rows = torch.zeros(mts * 16, 512, dtype=dt, device=dev)
-        L.check(lib.lgen_gemm(L.ptr(w13), L.ptr(hp), L.ptr(gp), M, mts, 2 * F, d, L.EPI_SWIGLU, code, mt, nt, kw, L.ptr(nw), L.ptr(ssq),
-                              d // 16, 1e-5, 0, L.stream()), "norm+swiglu")
-        L.check(lib.lgen_gemm(L.ptr(woutp), L.ptr(hp), L.ptr(rows), M, mts, 512, d, L.EPI_ROWS, code, mt, nt, kw, L.ptr(nw), L.ptr(ssq),
-                              d // 16, 1e-5, 0, L.stream()), "norm+rows")
-        torch.cuda.synchronize()
-        return gp, rows
-
-    generic = run()
-    monkeypatch.setenv("LGEN_GEMM_STEADY_NORM", "1")
-    steady = run()
-    assert torch.equal(generic[0], steady[0]) and torch.equal(generic[1], steady[1])
-    xn = O.rms_norm(h.float(), nw.cpu(), 1e-5, dt)
-    _close(steady[1][:M], O.linear(xn, wout.float(), dt), dt, "steady norm+rows", frac_ulp1=0.05)
-
-
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("interleave", [False, True])
-@pytest.mark.parametrize("B2,H,hd,grid,pos", [(2, 4, 64, 4, 0), (2, 4, 64, 4, 7), (33, 16, 64, 24, 300), (3, 8, 100, 4, 16)])
+@pytest.mark.parametrize("B2,H,hd,grid,pos", [(2, 4, 64, 4, 0), (2, 4, 64, 4, 7), (33, 16, 64, 24, 300), (3, 8, 100, 4, 16),
+                                               (192, 16, 64, 8, 40)])   # 3072 (row, head) items: persistent waves walk 1 or 2 items
 def test_qkv_rope_append_and_attention(dt, B2, H, hd, grid, pos, interleave):
     """wqkv GEMM + RoPE + cache append, then decode attention over the cache, vs the oracle."""
     from llamagen_amd.engine import pack_act, pack_weight, precompute_freqs_cis_2d, unpack_act
@@ -324,17 +287,20 @@ def test_qkv_rope_append_and_attention(dt, B2, H, hd, grid, pos, interleave):
     wp, xp, fr_d = pack_weight(w.to(dev)), pack_act(x.to(dev), mts), freqs.to(dev)  # keep alive across the launch
     L.check(L.lib().lgen_gemm_qkv_rope(L.ptr(wp), L.ptr(xp), L.ptr(q_d), L.ptr(kc_d),
                                        L.ptr(vc_d), L.ptr(fr_d), L.ptr(state), B2, mts, d, H, hd, hdp, S8, KVS, code,
-                                       min(mts, 4), 1, 4, 0, 0, 0, 0.0, L.stream()), "qkv")
+                                       min(mts, 4), 1, 4, 0, 0, 0, 0.0, 1, L.stream()), "qkv")
     qkv = O.linear(x.float(), w.float(), dt)
     xq, xk, xv = qkv.split([d, d, d], dim=-1)
     fr = freqs[pos:pos + 1]
+    xq_lin = xq.reshape(B2, H, hd)   # a 1-ulp flip of the linear output survives the rotation at ITS magnitude (see _close: mag)
     xq = O.apply_rotary_emb(xq.reshape(B2, 1, H, hd), fr, dt)
     xk = O.apply_rotary_emb(xk.reshape(B2, 1, H, hd), fr, dt)
-    _close(q_d[:B2, :, :hd], xq[:, 0], dt, "q rope")
+    _close(q_d[:B2, :, :hd], xq[:, 0], dt, "q rope", mag=xq_lin)
     kref, vref = kcache.float().clone(), vcache.float().clone()
     kref[:, :, pos] = xk[:, 0]
     vref[:, :, pos] = xv.reshape(B2, H, hd)
-    _close(kc_d[..., :hd], kref, dt, "k cache")
+    kmag = torch.zeros_like(kref)
+    kmag[:, :, pos] = qkv.split([d, d, d], dim=-1)[1].reshape(B2, H, hd).float()
+    _close(kc_d[..., :hd], kref, dt, "k cache", mag=kmag)
     _close(vc_d[..., :hd], vref, dt, "v cache")
     assert (kc_d[..., hd:] == 0).all() and (q_d[:, :, hd:] == 0).all()
     # attention over the (oracle-exact) cache contents so that errors do not compound
@@ -344,8 +310,9 @@ def test_qkv_rope_append_and_attention(dt, B2, H, hd, grid, pos, interleave):
     kcd = _kc(dt)
     variants = [(False, 0), (True, 0), (False, 1), (True, 1), (False, 2), (True, 3), (True, 4), (False, 5)]
     variants += [(um, v) for v, hpw in ((6, 2), (7, 4)) if H % hpw == 0 for um in (False, True)]  # round 3: 2 / 4 heads per workgroup
+    variants += [(um, v) for v in (8, 9, 10, 11, 12, 13) for um in (False, True)]  # round 4: persistent form (one / two 8-wave, one 4-wave workgroup per CU)
+    variants += [(False, -1), (True, -1)]   # the library's own choice for this shape
     for use_mask, variant in variants:
-        L.lib().lgen_set_attn_variant(variant)
         mask = torch.tril(torch.ones(S8, S8, dtype=torch.bool)).unsqueeze(0).repeat(B2, 1, 1)
         if use_mask:
             g = torch.Generator().manual_seed(13)
@@ -354,10 +321,9 @@ def test_qkv_rope_append_and_attention(dt, B2, H, hd, grid, pos, interleave):
         out = torch.zeros(d // kcd, mts, 64, kcd // 4, dtype=dt, device=dev)
         md = mask.to(dev).contiguous() if use_mask else None
         L.check(L.lib().lgen_attn_decode(L.ptr(q_d), L.ptr(kc_d), L.ptr(vc_d), L.ptr(out), L.ptr(state), L.ptr(md), 0, B2, mts, H,
-                                         hd, hdp, S8, KVS, code, L.stream()), "attn")
+                                         hd, hdp, S8, KVS, code, variant, L.stream()), "attn")
         ref = O.sdpa_math(xq.transpose(1, 2), kref, vref, mask[:, None, pos:pos + 1], dt)  # [B,H,1,hd]
         _close(unpack_act(out, B2), ref.transpose(1, 2).reshape(B2, d), dt, f"attn mask={use_mask} variant={variant}")
-    L.lib().lgen_set_attn_variant(2)
 
 
 @pytest.mark.parametrize("dt", DTYPES)
@@ -770,13 +736,13 @@ def test_attn_prefill_any_length(dt, B2, H, hd, T, use_mask):
     md = mask.to(dev).contiguous() if use_mask else None
     ref = O.sdpa_math(q, k, v, mask[:, None, :T, :T], dt)                        # [B2, H, T, hd]
     for mfma in ((1, 0) if dt == torch.bfloat16 else (1,)):  # bf16: the MFMA flash kernel (default) and the VALU kernels
-        L.lib().lgen_set_prefill_mfma(mfma)
+        L.lib().lgen_debug_set_prefill_mfma(mfma)
         out.zero_()
         L.check(L.lib().lgen_attn_prefill(L.ptr(q_d), L.ptr(kc_d), L.ptr(vc_d), L.ptr(out), L.ptr(md), T, B2, mts, H, hd, hdp, S8, 0,
                                           code, L.stream()), "attn_prefill")
         got = unpack_act(out, R).view(T, B2, H, hd).permute(1, 2, 0, 3)
         _close(got, ref, dt, f"attn_prefill T={T} hd={hd} mask={use_mask} mfma={mfma}", frac_ulp1=0.05)
-    L.lib().lgen_set_prefill_mfma(1)
+    L.lib().lgen_debug_set_prefill_mfma(1)
 
 
 @pytest.mark.parametrize("dt", DTYPES)

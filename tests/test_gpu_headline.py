@@ -188,17 +188,41 @@ def test_config2_gptl_bf16_four_batches_per_chain_logits_vs_oracle():
     recs, m = _teacher_forced(case, B, 4.0, early=2, late=[299], cond=cond)
     e = m._engine
     assert e.fuse_norm and e.MTs == 16 and e.S8 == 584
-    assert e._tiles("qkv", 3 * e.d, e.d) == (1, 4, 8) and e._tiles("w13", 2 * e.F, e.d) == (2, 4, 8)  # what bench.py replays
-    assert e._passes("qkv", 3 * e.d, (1, 4, 8)) == (3, 0) and e._passes("w13", 2 * e.F, (2, 4, 8)) == (3, 0)
-    assert e._passes("head", e.V, e._tiles("head", e.V, e.d)) == (8, 0)   # the persistent form is what ran
+    sched = e.gemm_schedule()   # round 4: the big-M tile family from 256 rows up
+    assert _pinned(16) == {k: tuple(v["shape(wm,wn,mtv,ntv,kb,stages,lw)"]) for k, v in sched.items()}, sched
     _check("config2_gptl_b256", recs)
+
+
+def test_config2_gptl_bf16_ten_batches_per_chain_logits_vs_oracle():
+    """Round 4 schedule (`bench.py --steps 20`: two chains of ten batches): 640 rows, MTs = 40, every decode GEMM on the big-M tile
+    family with the 640-row shapes (one round of <= 256 workgroups per launch), persistent decode attention (>= 256 rows): prefill, position 1 and position 299 on injected
+    cache contents, same bar as the 64-row test; the schedule the bench prints (`roofline_gemm.schedule`) is pinned here."""
+    case = dict(registry="GPT-L", kwargs=dict(vocab_size=16384, block_size=576, num_classes=1000, cls_token_num=1,
+                                              model_type="c2i"), wseed=21, lin_std=0.02)
+    B = 320
+    cond = torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(6))
+    recs, m = _teacher_forced(case, B, 4.0, early=1, late=[299], cond=cond)
+    e = m._engine
+    assert e.fuse_norm and e.MTs == 40 and e.S8 == 584
+    sched = e.gemm_schedule()
+    assert all(v["family"] == "tile" for v in sched.values()), sched
+    assert _pinned(40) == {k: tuple(v["shape(wm,wn,mtv,ntv,kb,stages,lw)"]) for k, v in sched.items()}, sched
+    _check("config2_gptl_b640", recs)
+
+
+def _pinned(min_mts):
+    """engine.TILE_SCHEDULES[min_mts] in gemm_schedule()'s naming: what bench.py must print to count as a tested schedule"""
+    from llamagen_amd.engine import TESTED_TILE_SCHEDULES, TILE_SCHEDULES
+    assert min_mts in TESTED_TILE_SCHEDULES
+    t = TILE_SCHEDULES[min_mts]
+    return {"wqkv": t["qkv"], "wo": t["wo"], "w13": t["w13"], "w2": t["w2"], "lm_head": t["head"]}
 
 
 @pytest.mark.parametrize("M", [64, 128, 256])
 def test_fused_norm_gemm_passes_bit_identical(M):
     """gemm_normpre.hip walks `passes` n-groups per workgroup with its normalised rows kept in registers (round 3).  The
     arithmetic per output element does not depend on the schedule: qkv (+RoPE+append), w1||w3 (+SwiGLU) and lm_head outputs at
-    GPT-L sizes must be BIT-identical for every (passes, double_buffer), including pass counts that do not divide the n-groups,
+    GPT-L sizes must be BIT-identical for every `passes` (explicit argument since ABI v7), including pass counts that do not divide the n-groups,
     and the one-pass result is held to the oracle."""
     from llamagen_amd.engine import pack_act, pack_weight, precompute_freqs_cis_2d, unpack_act
     from tests.test_gpu_gpt import _close, _rand
@@ -218,22 +242,19 @@ def test_fused_norm_gemm_passes_bit_identical(M):
     L.check(lib.lgen_ssq_pack(L.ptr(xp), L.ptr(ssq), mts, d, L.BF16, L.stream()), "ssq_pack")
     state = torch.tensor([pos, 0], dtype=torch.int32, device=dev)
 
-    def run(tile, passes, db):
+    def run(tile, passes):
         mt, nt = tile
         kc = torch.zeros(M, H, S8, 64, dtype=dt, device=dev)
         vc = torch.zeros(M, H, S8, 64, dtype=dt, device=dev)
         q = torch.zeros(mts * 16, H, 64, dtype=dt, device=dev)
         gp = torch.zeros(F // 32, mts, 64, 8, dtype=dt, device=dev)
         rows = torch.zeros(mts * 16, V, dtype=dt, device=dev)
-        L.check(lib.lgen_gemm_schedule_hint(passes, db), "hint")
         L.check(lib.lgen_gemm_qkv_rope(L.ptr(wqp), L.ptr(xp), L.ptr(q), L.ptr(kc), L.ptr(vc), L.ptr(fr_d), L.ptr(state), M, mts, d, H,
-                                       hd, 64, S8, 0, L.BF16, mt, nt, 8, L.ptr(nw_d), L.ptr(ssq), d // 16, 1e-5, L.stream()), "qkv")
-        L.check(lib.lgen_gemm_schedule_hint(passes, db), "hint")
+                                       hd, 64, S8, 0, L.BF16, mt, nt, 8, L.ptr(nw_d), L.ptr(ssq), d // 16, 1e-5, passes, L.stream()), "qkv")
         L.check(lib.lgen_gemm(L.ptr(w13), L.ptr(xp), L.ptr(gp), M, mts, 2 * F, d, L.EPI_SWIGLU, L.BF16, mt, nt, 8, L.ptr(nw_d),
-                              L.ptr(ssq), d // 16, 1e-5, 0, L.stream()), "w13")
-        L.check(lib.lgen_gemm_schedule_hint(passes, db), "hint")
+                              L.ptr(ssq), d // 16, 1e-5, 0, passes, L.stream()), "w13")
         L.check(lib.lgen_gemm(L.ptr(whp), L.ptr(xp), L.ptr(rows), M, mts, V, d, L.EPI_ROWS, L.BF16, mt, nt, 8, L.ptr(nw_d),
-                              L.ptr(ssq), d // 16, 1e-5, 0, L.stream()), "head")
+                              L.ptr(ssq), d // 16, 1e-5, 0, passes, L.stream()), "head")
         torch.cuda.synchronize()
         return q, kc[:, :, pos].clone(), vc[:, :, pos].clone(), gp, rows
 
@@ -245,7 +266,7 @@ def test_fused_norm_gemm_passes_bit_identical(M):
     eyep = pack_weight(torch.eye(d, dtype=dt).to(dev))
     xrows = torch.zeros(mts * 16, d, dtype=dt, device=dev)
     L.check(lib.lgen_gemm(L.ptr(eyep), L.ptr(xp), L.ptr(xrows), M, mts, d, d, L.EPI_ROWS, L.BF16, 2, 4, 8, L.ptr(nw_d), L.ptr(ssq),
-                          d // 16, 1e-5, 0, L.stream()), "norm + identity")
+                          d // 16, 1e-5, 0, 1, L.stream()), "norm + identity")
     xn_ref = O.rms_norm(x.float(), nw, 1e-5, dt)
     xn = xrows[:M].float().cpu()
     dx = (xn - xn_ref).abs()
@@ -261,11 +282,11 @@ def test_fused_norm_gemm_passes_bit_identical(M):
     for tile in [(2, 4), (1, 4), (2, 2), (4, 2)]:  # qkv (4, 2) has no multi-pass form (register budget): falls back to one pass
         if tile[0] > mts:
             continue
-        base = run(tile, 1, 0)
-        for passes, db in [(2, 0), (2, 1), (3, 0), (3, 1), (5, 1), (7, 0), (64, 1)]:
-            got = run(tile, passes, db)
+        base = run(tile, 1)
+        for passes in (2, 3, 5, 7, 64):
+            got = run(tile, passes)
             for name, a, b in zip(("q", "k", "v", "swiglu", "logits"), base, got):
-                assert torch.equal(a, b), (tile, passes, db, name, (a.float() - b.float()).abs().max().item())
+                assert torch.equal(a, b), (tile, passes, name, (a.float() - b.float()).abs().max().item())
         # the K split (8 waves x 4 chunks, summed wave 0..7) is the same for every workgroup shape: tiles agree bit for bit too
         if first is None:
             first = base
@@ -276,6 +297,145 @@ def test_fused_norm_gemm_passes_bit_identical(M):
         _close(rows[:M], ref_rows, dt, f"norm+lm_head {tile}", frac_ulp1=0.05)
         _close(unpack_act(gp, M), ref_gp, dt, f"norm+swiglu {tile}", frac_ulp1=0.08, ulps=3)
         _close(v, ref_v, dt, f"v row {tile}", frac_ulp1=0.05)
+
+
+TILE_NORM = [(4, 1, 1, 3, 4, 4, 4), (4, 1, 1, 6, 4, 3, 4), (4, 1, 2, 8, 2, 4, 4), (4, 1, 1, 4, 4, 4, 4), (4, 1, 1, 6, 2, 4, 4),
+             (4, 1, 1, 8, 2, 4, 4), (4, 1, 2, 4, 2, 4, 4), (4, 1, 2, 6, 2, 4, 4), (4, 1, 1, 2, 4, 4, 4), (4, 1, 1, 3, 4, 4, 0)]
+TILE_PLAIN = [(2, 2, 1, 1, 4, 4, 4), (2, 2, 1, 2, 4, 4, 4), (2, 2, 2, 1, 4, 4, 4), (2, 2, 2, 2, 4, 4, 4), (2, 2, 2, 2, 2, 4, 4),
+              (4, 1, 1, 2, 4, 4, 4), (2, 2, 1, 1, 4, 4, 0), (2, 2, 4, 1, 4, 4, 4), (2, 2, 4, 2, 2, 4, 4)]
+
+
+@pytest.mark.parametrize("M", [128, 256, 512, 640])
+def test_tile_gemm_family_vs_oracle_and_bit_identical_across_shapes(M):
+    """Big-M tile family (csrc/gemm_tile.hip, round 4) at GPT-L sizes: every instantiated workgroup shape of lgen_gemm_tile /
+    lgen_gemm_qkv_rope_tile -- loader waves or not, any tile, any ring depth -- accumulates an output element in ONE wave over k
+    in order, so ALL shapes must agree BIT for bit; the first is held to the oracle: fused RMSNorm (scales bit-identical to the
+    skinny kernels': same statistics, same summation order) + wqkv + RoPE + KV append, + w1||w3 + SwiGLU, + lm_head rows, and the
+    plain form wo / w2 + residual + the next norm's statistics.  (F = 2816: K = 88 chunks for w2; N = 5632 does not divide every
+    tile width: the ragged last n-group is exercised.)"""
+    from llamagen_amd.engine import pack_act, pack_weight, precompute_freqs_cis_2d, unpack_act
+    from tests.test_gpu_gpt import _close, _rand
+    L, dev = _L(), _dev()
+    lib = L.lib()
+    dt, d, H, hd, F, V, grid, pos = torch.bfloat16, 1024, 16, 64, 2816, 2048, 24, 77
+    S8 = O.find_multiple(1 + grid * grid, 8)
+    mts = M // 16
+    x = _rand((M, d), dt, 61, 1.3)
+    nw = (1 + 0.1 * _rand((d,), torch.float32, 62)).to(dt)
+    wq, w1, w3, wh = _rand((3 * d, d), dt, 63, 0.03), _rand((F, d), dt, 64, 0.03), _rand((F, d), dt, 65, 0.03), _rand((V, d), dt, 66, 0.03)
+    wo, w2 = _rand((d, d), dt, 67, 0.03), _rand((d, F), dt, 68, 0.02)
+    a_in, g_in, h0 = _rand((M, d), dt, 69, 1.0), _rand((M, F), dt, 70, 0.7), _rand((M, d), dt, 71, 1.5)
+    freqs = precompute_freqs_cis_2d(grid, hd, 10000.0, 1)
+    xp, nw_d, fr_d = pack_act(x.to(dev), mts), nw.to(dev), freqs.to(dev)
+    ap, gpin, hp0 = pack_act(a_in.to(dev), mts), pack_act(g_in.to(dev), mts), pack_act(h0.to(dev), mts)
+    wqp, whp, wop, w2p = (pack_weight(t.to(dev)) for t in (wq, wh, wo, w2))
+    w13 = torch.stack([pack_weight(w1.to(dev)), pack_weight(w3.to(dev))], dim=1).flatten(0, 1).contiguous()
+    ssq = torch.full((mts * 16, L.SSQ_STRIDE), float("nan"), device=dev)
+    L.check(lib.lgen_ssq_pack(L.ptr(xp), L.ptr(ssq), mts, d, L.BF16, L.stream()), "ssq_pack")
+    state = torch.tensor([pos, 0], dtype=torch.int32, device=dev)
+
+    def run_norm(s):
+        kc = torch.zeros(M, H, S8, 64, dtype=dt, device=dev)
+        vc = torch.zeros(M, H, S8, 64, dtype=dt, device=dev)
+        q = torch.zeros(mts * 16, H, 64, dtype=dt, device=dev)
+        gp = torch.zeros(F // 32, mts, 64, 8, dtype=dt, device=dev)
+        rows = torch.zeros(mts * 16, V, dtype=dt, device=dev)
+        rcs = [lib.lgen_gemm_qkv_rope_tile(L.ptr(wqp), L.ptr(xp), L.ptr(q), L.ptr(kc), L.ptr(vc), L.ptr(fr_d), L.ptr(state), M, mts, d,
+                                           H, hd, 64, S8, 0, L.BF16, *s, L.ptr(nw_d), L.ptr(ssq), d // 16, 1e-5, L.stream())]
+        if s[3] % 2 == 0:
+            rcs.append(lib.lgen_gemm_tile(L.ptr(w13), L.ptr(xp), L.ptr(gp), M, mts, 2 * F, d, L.EPI_SWIGLU, L.BF16, *s, L.ptr(nw_d),
+                                          L.ptr(ssq), d // 16, 1e-5, 0, L.stream()))
+        else:
+            gp = None
+        rcs.append(lib.lgen_gemm_tile(L.ptr(whp), L.ptr(xp), L.ptr(rows), M, mts, V, d, L.EPI_ROWS, L.BF16, *s, L.ptr(nw_d),
+                                      L.ptr(ssq), d // 16, 1e-5, 0, L.stream()))
+        torch.cuda.synchronize()
+        if any(rc == L.ERR_UNSUPPORTED for rc in rcs):
+            return None
+        assert all(rc == 0 for rc in rcs), (s, rcs)
+        kw = kc[:, :, pos].clone()
+        vw = vc[:, :, pos].clone()
+        kc[:, :, pos] = 0
+        vc[:, :, pos] = 0
+        assert not kc.any() and not vc.any(), s     # nothing but slot `pos` was written
+        return dict(q=q, k=kw, v=vw, swiglu=gp, logits=rows)
+
+    def run_plain(s):
+        out = {}
+        for name, wp_, xin, K in (("wo", wop, ap, d), ("w2", w2p, gpin, F)):
+            hp = hp0.clone()
+            so = torch.full((mts * 16, L.SSQ_STRIDE), float("nan"), device=dev)
+            rc = lib.lgen_gemm_tile(L.ptr(wp_), L.ptr(xin), L.ptr(hp), M, mts, d, K, L.EPI_RES, L.BF16, *s, 0, 0, 0, 0.0, L.ptr(so),
+                                    L.stream())
+            torch.cuda.synchronize()
+            if rc == L.ERR_UNSUPPORTED:
+                return None
+            assert rc == 0, (s, rc)
+            out[name], out[name + "_ssq"] = hp, so[:, : d // 16].clone()
+        return out
+
+    # the kernel's own normalised activations through an identity weight (exact): bit-identical to the skinny kernels' (same scales)
+    eyep = pack_weight(torch.eye(d, dtype=dt).to(dev))
+    xr_t = torch.zeros(mts * 16, d, dtype=dt, device=dev)
+    xr_s = torch.zeros(mts * 16, d, dtype=dt, device=dev)
+    L.check(lib.lgen_gemm_tile(L.ptr(eyep), L.ptr(xp), L.ptr(xr_t), M, mts, d, d, L.EPI_ROWS, L.BF16, 4, 1, 1, 4, 4, 4, 4, L.ptr(nw_d),
+                               L.ptr(ssq), d // 16, 1e-5, 0, L.stream()), "tile norm + identity")
+    L.check(lib.lgen_gemm(L.ptr(eyep), L.ptr(xp), L.ptr(xr_s), M, mts, d, d, L.EPI_ROWS, L.BF16, 2, 4, 8, L.ptr(nw_d), L.ptr(ssq),
+                          d // 16, 1e-5, 0, 1, L.stream()), "skinny norm + identity")
+    assert torch.equal(xr_t, xr_s)
+    xn = xr_t[:M].float().cpu()
+    xn_ref = O.rms_norm(x.float(), nw, 1e-5, dt)
+    dx = (xn - xn_ref).abs()
+    assert (dx > 0).float().mean().item() < 1e-3 and (dx <= torch.maximum(xn.abs(), xn_ref.abs()) * 2.0 ** -6 * 1.01).all()
+
+    qkv = O.linear(xn, wq.float(), dt)
+    xq, xk, xv = qkv.split([d, d, d], dim=-1)
+    fr = freqs[pos:pos + 1]
+    ref_q = O.apply_rotary_emb(xq.reshape(M, 1, H, hd), fr, dt)[:, 0]
+    ref_k = O.apply_rotary_emb(xk.reshape(M, 1, H, hd), fr, dt)[:, 0]
+    a1, a3 = O.linear(xn, w1.float(), dt), O.linear(xn, w3.float(), dt)
+    ref_gp = O._rnd(O._rnd(torch.nn.functional.silu(a1), dt) * a3, dt)
+    ref_rows = O.linear(xn, wh.float(), dt)
+    first, nrun = None, 0
+    for s in TILE_NORM:
+        got = run_norm(s)
+        if got is None:      # shape does not divide this M / exceeds the LDS budget: the library says so, nothing ran
+            continue
+        nrun += 1
+        if first is None:
+            first = got
+            _close(got["q"][:M], ref_q, dt, f"q {s}", frac_ulp1=0.05, mag=qkv[:, :d].reshape(M, H, hd))
+            _close(got["k"], ref_k, dt, f"k row {s}", frac_ulp1=0.05, mag=qkv[:, d:2 * d].reshape(M, H, hd))
+            _close(got["v"], xv.reshape(M, H, hd), dt, f"v row {s}", frac_ulp1=0.05)
+            _close(got["logits"][:M], ref_rows, dt, f"norm+lm_head {s}", frac_ulp1=0.05)
+        for name in ("q", "k", "v", "logits", "swiglu"):
+            if got[name] is None:
+                continue
+            if first[name] is None:
+                first[name] = got[name]
+                _close(unpack_act(got["swiglu"], M), ref_gp, dt, f"norm+swiglu {s}", frac_ulp1=0.08, ulps=3)
+            assert torch.equal(first[name], got[name]), (s, name, (first[name].float() - got[name].float()).abs().max().item())
+    assert nrun >= 4 and first["swiglu"] is not None, nrun
+
+    firstp, nrun = None, 0
+    for s in TILE_PLAIN:
+        got = run_plain(s)
+        if got is None:
+            continue
+        nrun += 1
+        if firstp is None:
+            firstp = got
+            for name, w_, xin in (("wo", wo, a_in), ("w2", w2, g_in)):
+                lin = O.linear(xin.float(), w_.float(), dt)
+                ref = O._rnd(h0.float() + lin, dt)
+                hrows = unpack_act(got[name], M)
+                _close(hrows, ref, dt, f"{name}+res {s}", frac_ulp1=0.05, mag=lin)
+                # statistics of the rows the kernel wrote: one fp32 partial per 16 columns, fixed order inside the tile
+                part = hrows.float().cpu().pow(2).reshape(M, d // 16, 16).sum(-1)
+                assert torch.allclose(got[name + "_ssq"][:M].cpu(), part, rtol=1e-5, atol=1e-6), name
+        for name in firstp:
+            assert torch.equal(firstp[name], got[name]), (s, name)
+    assert nrun >= 3, nrun
 
 
 @pytest.mark.parametrize("d,H,M,mt", [(1024, 16, 64, 1), (1280, 20, 64, 1), (1536, 24, 64, 1), (768, 12, 64, 1),
@@ -304,7 +464,7 @@ def test_qkv_fused_norm_rope_append_vs_oracle(d, H, M, mt, pos):
     q = torch.zeros(mts * 16, H, 64, dtype=dt, device=dev)
     state = torch.tensor([pos, 0], dtype=torch.int32, device=dev)
     L.check(lib.lgen_gemm_qkv_rope(L.ptr(wp), L.ptr(xp), L.ptr(q), L.ptr(kc), L.ptr(vc), L.ptr(fr_d), L.ptr(state), M, mts, d, H,
-                                   hd, 64, S8, 0, L.BF16, mt, 4, 8, L.ptr(nw_d), L.ptr(ssq), d // 16, 1e-5, L.stream()), "qkv fused")
+                                   hd, 64, S8, 0, L.BF16, mt, 4, 8, L.ptr(nw_d), L.ptr(ssq), d // 16, 1e-5, 1, L.stream()), "qkv fused")
     xn = O.rms_norm(x.float(), nw, 1e-5, dt)
     qkv = O.linear(xn, w.float(), dt)
     xq, xk, xv = qkv.split([d, d, d], dim=-1)

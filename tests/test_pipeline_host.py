@@ -4,6 +4,7 @@ The lanes are stand-ins that "generate" ids = label * 1000 + token position, so 
 came from."""
 import torch
 
+from llamagen_amd.generate import PadBatch
 from llamagen_amd.pipeline import SamplingPipeline
 
 
@@ -18,7 +19,10 @@ class _Lane:
 
     def start(self, job_id, cond, max_new_tokens, decode_shape, gen_kw):
         # what generate_iter does with `_more_conds` (the other batches of the chain, evaluated in RNG order after the first)
-        parts = [cond] + [c() if callable(c) else c for c in (gen_kw.get("_more_conds") or [])]
+        # (PadBatch: filler of an incomplete last chain -- valid conditioning, no noise draws, rows dropped)
+        more = gen_kw.get("_more_conds") or []
+        self.pads = sum(isinstance(c, PadBatch) for c in more)
+        parts = [cond] + [c.value[0] if isinstance(c, PadBatch) else (c() if callable(c) else c) for c in more]
         if any(c.shape != cond.shape for c in parts):
             raise ValueError("batches that share a chain must have the same size")
         cond = torch.cat(parts)
@@ -67,8 +71,8 @@ def test_two_batches_per_chain_group_pad_and_split():
     assert [(c[0][0], c[0][1]) for c in chains] == [(0, 2), (2, 2), (4, 1)]  # (first batch, batches in the chain)
     for (first, n, rows), cond, shape in chains:
         assert rows == 3 and cond.shape[0] == 6 and shape == [6, 8, 2, 2]  # every chain has the full chain shape
-        want = torch.cat([conds[first + i] for i in range(n)] + [conds[first + n - 1]] * (2 - n))
-        assert torch.equal(cond, want)  # an incomplete chain repeats its last batch
+        want = torch.cat([conds[first + i] for i in range(n)] + [conds[first]] * (2 - n))
+        assert torch.equal(cond, want)  # an incomplete chain is filled up with PadBatch copies of its first batch (no noise drawn for them)
     assert sorted(seen) == [0, 1, 2, 3, 4] and len(out) == 5  # on_done once per BATCH; the padding is dropped
     for i, (ids, img) in enumerate(out):
         assert torch.equal(ids[:, 0] // 1000, conds[i]) and tuple(ids.shape) == (3, 4) and tuple(img.shape) == (3, 3, 2, 2)

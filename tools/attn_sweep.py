@@ -15,6 +15,6 @@ ROWS = int(os.environ.get("ROWS", "128"))
 gpt.setup_caches(ROWS, 1 + N, torch.bfloat16)
 nbytes, nl = bench.attention_bytes_per_generate(gpt.config, ROWS, N)
 for v in [int(a) for a in sys.argv[1:]] or [2, 3, 1, 0, 4, 5]:
-    L.lib().lgen_set_attn_variant(v)
+    gpt._engine.attn_variant = v
     sec, launches, per_pos = bench.measure_attention(gpt, ROWS, N)
     print(f"variant {v}: avg {sec / launches * 1e6:6.2f} us  {nbytes / sec / 1e9:7.1f} GB/s  frac {nbytes / sec / 8e12:.3f}  {per_pos}", flush=True)

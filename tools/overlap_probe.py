@@ -1,0 +1,143 @@
+"""Do the kernels of two decode chains really run side by side?  (development aid, round 4)
+
+Two engines (shared weights, own KV slabs) on two HIP streams.  Graph A = the 24 attention launches of a decode step at position P,
+graph G = the 24 x 4 GEMM launches + lm_head of a decode step, graph V = one decode_code() of 32 images.  Each graph is timed alone
+and in pairs on two streams (A|G, A|A, G|G, A|V, G|V): perfect overlap = max of the two, none = their sum.
+    ROWS=256 POS=300 python tools/overlap_probe.py
+"""
+import os
+import sys
+import time
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from llamagen_amd import _lib as L  # noqa: E402
+
+ROWS = int(os.environ.get("ROWS", "256"))
+POS = int(os.environ.get("POS", "300"))
+REPS = 30
+
+
+def attn_only(e):
+    lib, st = e.lib, L.stream()
+    for i in range(e.L):
+        L.check(lib.lgen_attn_decode(L.ptr(e.qbuf), L.ptr(e.k_cache[i]), L.ptr(e.v_cache[i]), L.ptr(e.ap), L.ptr(e.state), 0, 0,
+                                     e.B2, e.MTs, e.H, e.hd, e.hdp, e.S8, e.kvs, e.dt, -1, st), "attn")
+
+
+def gemms_only(e):
+    lib, st, dt, M, mts = e.lib, L.stream(), e.dt, e.B2, e.MTs
+    d, F, H, hd, hdp, S8 = e.d, e.F, e.H, e.hd, e.hdp, e.S8
+    tq, to, t13, t2, th = (e._tiles("qkv", 3 * d, d), e._tiles("wo", d, d), e._tiles("w13", 2 * F, d), e._tiles("w2", d, F),
+                           e._tiles("head", e.V, d))
+    sq, s13, sh = e._passes("qkv", 3 * d, tq), e._passes("w13", 2 * F, t13), e._passes("head", e.V, th)
+    bq, bo, b13, b2, bh = (e._tile_shape(k) for k in ("qkv", "wo", "w13", "w2", "head"))
+    e.ssq_parts = d // 16
+    for i, w in enumerate(e.layers):
+        rc = L.ERR_UNSUPPORTED
+        if bq is not None:
+            rc = lib.lgen_gemm_qkv_rope_tile(L.ptr(w["wqkv"]), L.ptr(e.hp), L.ptr(e.qbuf), L.ptr(e.k_cache[i]), L.ptr(e.v_cache[i]),
+                                             L.ptr(e.freqs_cis), L.ptr(e.state), M, mts, d, H, hd, hdp, S8, e.kvs, dt, *bq,
+                                             L.ptr(w["an"]), L.ptr(e.ssq), e.ssq_parts, e.eps, st)
+        if rc == L.ERR_UNSUPPORTED:
+            if sq[0] > 1:
+                lib.lgen_gemm_schedule_hint(sq[0], sq[1])
+            L.check(lib.lgen_gemm_qkv_rope(L.ptr(w["wqkv"]), L.ptr(e.hp), L.ptr(e.qbuf), L.ptr(e.k_cache[i]), L.ptr(e.v_cache[i]),
+                                           L.ptr(e.freqs_cis), L.ptr(e.state), M, mts, d, H, hd, hdp, S8, e.kvs, dt, tq[0], tq[1], tq[2],
+                                           L.ptr(w["an"]), L.ptr(e.ssq), e.ssq_parts, e.eps, 1, st), "qkv")
+        e.gemm(w["wo"], e.ap, e.hp, M, mts, d, d, L.EPI_RES, to, ssq_out=e.ssq, tile=bo)
+        e.gemm(w["w13"], e.hp, e.gp, M, mts, 2 * F, d, L.EPI_SWIGLU, t13, norm_w=w["fn"], sched=s13, tile=b13)
+        e.gemm(w["w2"], e.gp, e.hp, M, mts, d, F, L.EPI_RES, t2, ssq_out=e.ssq, tile=b2)
+    e.gemm(e.out_w, e.hp, e.logits, M, mts, e.V, d, L.EPI_ROWS, th, norm_w=e.norm_w, sched=sh, tile=bh)
+
+
+def capture(fn, stream):
+    with torch.cuda.stream(stream):
+        fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=stream):
+        fn()
+    torch.cuda.synchronize()
+    return g
+
+
+def timed(pairs):
+    """pairs: [(graph, stream), ...] replayed REPS times each, interleaved; us per replay round"""
+    best = 1e9
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(REPS):
+            for g, s in pairs:
+                with torch.cuda.stream(s):
+                    g.replay()
+        torch.cuda.synchronize()
+        best = min(best, (time.perf_counter() - t0) / REPS * 1e6)
+    return best
+
+
+def main():
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    torch.set_grad_enabled(False)
+    gpt, vq = bench.build_models(dev, 0)
+    N = 576
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    engs = []
+    for view in (gpt, gpt.lane_view()):
+        view.setup_caches(ROWS, 1 + N, torch.bfloat16)
+        e = view._engine
+        e.k_cache.normal_(0, 1)
+        e.v_cache.normal_(0, 1)
+        e.qbuf.normal_(0, 1)
+        e.hp.normal_(0, 1)
+        e.ap.normal_(0, 1)
+        e.gp.normal_(0, 0.1)
+        e.ssq.fill_(16.0)
+        e.state.copy_(torch.tensor([POS, POS], dtype=torch.int32, device=dev))
+        engs.append((view, e))
+    (_, e1), (_, e2) = engs
+    codes = torch.randint(0, 16384, (32, N), device=dev)
+    A1, A2 = capture(lambda: attn_only(e1), s1), capture(lambda: attn_only(e2), s2)
+    G1, G2 = capture(lambda: gemms_only(e1), s1), capture(lambda: gemms_only(e2), s2)
+
+    def vqd():
+        vq.decode_code(codes, (32, 8, 24, 24))
+    with torch.cuda.stream(s2):
+        vqd()
+    torch.cuda.synchronize()
+    tA, tG = timed([(A1, s1)]), timed([(G1, s1)])
+    print(f"rows {ROWS} pos {POS}: A alone {tA:8.1f} us   G alone {tG:8.1f} us   (tile {e1._tile_shape('qkv')})", flush=True)
+    for name, pairs, parts in (("A|G", [(A1, s1), (G2, s2)], (tA, tG)), ("A|A", [(A1, s1), (A2, s2)], (tA, tA)),
+                               ("G|G", [(G1, s1), (G2, s2)], (tG, tG))):
+        t = timed(pairs)
+        print(f"  {name}: {t:8.1f} us   sum {sum(parts):8.1f}  max {max(parts):8.1f}  -> overlap {(sum(parts) - t) / min(parts):5.2f} "
+              f"(1 = the shorter one fully hidden)", flush=True)
+    # decoder beside a chain: REPS x A (or G) on s1 while one decode_code() of 32 images runs on s2
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with torch.cuda.stream(s2):
+        vqd()
+    torch.cuda.synchronize()
+    tV = (time.perf_counter() - t0) * 1e6
+    for name, g, tg in (("A", A1, tA), ("G", G1, tG)):
+        reps = max(1, int(tV / tg))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.cuda.stream(s2):
+            vqd()
+        for _ in range(reps):
+            with torch.cuda.stream(s1):
+                g.replay()
+        torch.cuda.synchronize()
+        t = (time.perf_counter() - t0) * 1e6
+        print(f"  V|{name}: V alone {tV:8.1f} us, {reps} x {name} alone {reps * tg:8.1f} us, together {t:8.1f} us -> overlap "
+              f"{(tV + reps * tg - t) / min(tV, reps * tg):5.2f}", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -27,6 +27,6 @@ for pos in bench.PMC_POSITIONS(N, T):
     state.copy_(torch.tensor([pos, pos], dtype=torch.int32, device=dev))
     for i in range(nl):
         L.check(lib.lgen_attn_decode(L.ptr(q), L.ptr(kc[i]), L.ptr(vc[i]), L.ptr(out), L.ptr(state), 0, 0, rows, mts, H, hd, hd, S8, hd,
-                                     L.BF16, L.stream()), "attn")
+                                     L.BF16, -1, L.stream()), "attn")
     torch.cuda.synchronize()
 print("done")

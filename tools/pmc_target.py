@@ -28,6 +28,6 @@ for pos in (63, 287, 575):
     e.state.copy_(torch.tensor([pos, pos], dtype=torch.int32, device=dev))
     for i in range(e.L):
         L.check(e.lib.lgen_attn_decode(L.ptr(e.qbuf), L.ptr(e.k_cache[i]), L.ptr(e.v_cache[i]), L.ptr(e.ap), L.ptr(e.state), 0, 0,
-                                       2 * B, e.MTs, e.H, e.hd, e.hdp, e.S8, e.kvs, e.dt, L.stream()), "attn")
+                                       2 * B, e.MTs, e.H, e.hd, e.hdp, e.S8, e.kvs, e.dt, -1, L.stream()), "attn")
     torch.cuda.synchronize()
 print("done")

@@ -313,13 +313,13 @@ __global__ __launch_bounds__(64 * ATT_NW * HPW, (ATT_CH <= 2 ? 4 : 2)) void attn
             D::unpack(KB[j], kf);                                                                  \
             float dot = 0.f;                                                                       \
             _Pragma("unroll") for (int e = 0; e < EPL; ++e) dot = fmaf(qf[e], kf[e] * a.sf, dot);  \
-            _Pragma("unroll") for (int o = 1; o < LPK; o <<= 1) dot += __shfl_xor(dot, o, 64);     \
+            dot = group_sum<LPK>(dot);                                                             \
             bool vis = key < kvlen;                                                                \
             if (pm && vis && key < a.mask_len) vis = pm[key] != 0;                                 \
             s[j] = vis ? dot : -1e30f;                                                             \
             tmax = fmaxf(tmax, s[j]);                                                              \
         }                                                                                          \
-        _Pragma("unroll") for (int o = LPK; o < 64; o <<= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, o, 64)); \
+        tmax = across_groups<LPK>(tmax, [](float x, float y) { return fmaxf(x, y); });              \
         const float m_new = fmaxf(m_run, tmax);                                                    \
         const float scale = D::fexp(m_run - m_new);                                                \
         l_run *= scale;                                                                            \
@@ -450,15 +450,13 @@ __global__ __launch_bounds__(64 * NWV) void attn_decode_persist_kernel(AttnArgs 
             float dot = 0.f;
 #pragma unroll
             for (int e = 0; e < EPL; ++e) dot = fmaf(qf[e], kf[e] * a.sf, dot);
-#pragma unroll
-            for (int o = 1; o < LPK; o <<= 1) dot += __shfl_xor(dot, o, 64);
+            dot = group_sum<LPK>(dot);
             bool vis = key < kvlen;
             if (pm && vis && key < a.mask_len) vis = pm[key] != 0;
             s[j] = vis ? dot : -1e30f;
             tmax = fmaxf(tmax, s[j]);
         }
-#pragma unroll
-        for (int o = LPK; o < 64; o <<= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, o, 64));
+        tmax = across_groups<LPK>(tmax, [](float x, float y) { return fmaxf(x, y); });
         const float m_new = fmaxf(m_run, tmax);
         const float scale = D::fexp(m_run - m_new);
         l_run *= scale;
@@ -478,12 +476,10 @@ __global__ __launch_bounds__(64 * NWV) void attn_decode_persist_kernel(AttnArgs 
     auto end_group = [&]() {                  // returns false when this wave has no item left
         if (++cg < ngroups) return true;
         // item done: combine the KPL key groups of the wave (lanes with equal `part`), normalise, store
+        auto add = [](float x, float y) { return x + y; };
+        l_run = across_groups<LPK>(l_run, add);
 #pragma unroll
-        for (int o = LPK; o < 64; o <<= 1) {
-            l_run += __shfl_xor(l_run, o, 64);
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
-        }
+        for (int e = 0; e < EPL; ++e) acc[e] = across_groups<LPK>(acc[e], add);
         if (lane < LPK) {
             const int b = ci / a.H, h = ci - b * a.H;
 #pragma unroll

@@ -234,4 +234,44 @@ LGEN_DEV float wave_max(float v) {
     return v;
 }
 
+// Cross-lane butterflies without the LDS crossbar (__shfl_xor compiles to ds_bpermute_b32: an LDS instruction and an lgkmcnt round
+// trip of ~100 cycles per step -- with one wave per SIMD nothing hides it; round 4).  DPP modifiers fold into the consuming VALU
+// op (v_add_f32_dpp ...); the 16- and 32-lane exchanges are gfx950's v_permlane16_swap / v_permlane32_swap (both operands = the
+// value: the two results are "rows 0,0,2,2 | 1,1,3,3" resp. "low half twice | high half twice" of it).
+template <int CTRL>
+LGEN_DEV float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140, DPP_ROR8 = 0x128;
+// (inline asm: with the builtin, hipcc of ROCm 7.2 loses track of which register holds which result when both inputs are the same
+// value -- `op(r0, r0)` / a stale copy after the swap; found with tools/ubench/dpp_check.hip.  The s_nop covers the VALU-write ->
+// permlane-swap-read wait states the compiler would have inserted.)
+LGEN_DEV void lane_swap16(float v, float& a, float& b) {   // a, b: the values of this lane's row pair (xor 16 partner in one of them)
+    a = v; b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+LGEN_DEV void lane_swap32(float v, float& a, float& b) {
+    a = v; b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+// sum over the LPK lanes of a key group (LPK = 4 .. 32 consecutive lanes, aligned): every lane ends with the group total.  Bitwise
+// equal to the __shfl_xor(1, 2, 4, ...) butterfly: after each step all lanes of a sub-group hold the SAME partial, and a + b == b + a.
+template <int LPK>
+LGEN_DEV float group_sum(float v) {
+    v += dpp_f<DPP_XOR1>(v);
+    v += dpp_f<DPP_XOR2>(v);
+    if constexpr (LPK >= 8) v += dpp_f<DPP_HALF_MIRROR>(v);
+    if constexpr (LPK >= 16) v += dpp_f<DPP_MIRROR>(v);
+    if constexpr (LPK >= 32) { float a, b; lane_swap16(v, a, b); v = a + b; }
+    return v;
+}
+// combine across the 64 / LPK key groups of a wave, lane-aligned (partner = lane ^ LPK, ^ 2 LPK, ...), LPK >= 8
+template <int LPK, typename F>
+LGEN_DEV float across_groups(float v, F&& op) {
+    if constexpr (LPK <= 8) v = op(v, dpp_f<DPP_ROR8>(v));
+    if constexpr (LPK <= 16) { float a, b; lane_swap16(v, a, b); v = op(a, b); }
+    { float a, b; lane_swap32(v, a, b); v = op(a, b); }
+    return v;
+}
+
 #define LGEN_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)

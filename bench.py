@@ -365,7 +365,7 @@ def live_traffic(rows, timeout_s=150):
                 seq = []
                 for f in glob.glob(os.path.join(td, "**", "*counter_collection.csv"), recursive=True):
                     for row in csv.DictReader(open(f)):
-                        if row["Counter_Name"] == counter and "attn_decode_kernel" in row["Kernel_Name"]:
+                        if row["Counter_Name"] == counter and "attn_decode" in row["Kernel_Name"]:   # attn_decode_kernel / attn_decode_persist_kernel
                             seq.append((int(row["Dispatch_Id"]), float(row["Counter_Value"])))
                 seq.sort()
                 vals[counter] = [v for _, v in seq]
@@ -620,7 +620,7 @@ def main():
             pa = pmc.get("attn_decode_kernel")
             traffic = None if pa is None else int(pa["fetch_over_algorithmic"] * nbytes / launches + pa["write_bytes_per_launch"])
             tsrc = None if pa is None else pa.get("source")
-            res["roofline"] = {"bound": "hbm", "kernel": "attn_decode_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+            res["roofline"] = {"bound": "hbm", "kernel": "attn_decode_persist_kernel" if rows >= 256 else "attn_decode_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                                "traffic": traffic, "traffic_source": tsrc,
                                "avg_launch_us": round(sec / launches * 1e6, 2),
@@ -730,7 +730,7 @@ def main():
 
 HBM_BUDGET_BYTES = 180e9   # KV slabs + noise of the chains in flight per GPU (288 GB HBM3E minus weights, decoder activations, slack)
 MFMA_BF16_PEAK_TFLOPS = 2500.0
-PMC_JSON = "r03_pmc.json"
+PMC_JSON = "r04_pmc.json"
 
 
 def PMC_POSITIONS(N, T=1):

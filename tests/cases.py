@@ -124,3 +124,57 @@ def make_topp_tie_rows(V=16384, rows=6, seed=31):
         frac = (0.37, 0.5, 0.81, 0.12, 0.66, 0.95)[r % 6]
         tops.append(float(p[perm[:nbig]].sum() + (frac * ntie) * p[perm[nbig]]))
     return l, tops
+
+
+# ---- BASELINE configs[2..4] at FULL depth, pinned to the reference (round 4) ------------------------------------------------
+# GPT-XXL (48 layers) / GPT-3B (24, head_dim 100) / GPT-XL t2i (36, T = 120, 512 px) in bf16 with two images (four CFG rows):
+# prefill, two early teacher-forced decode positions, one LATE position on injected K/V cache contents.  The reference produces
+# the CFG-mixed logits of every step in the build container (tests/golden/make_golden.py full_depth); the oracle (CPU) and the HIP
+# path (GPU, no CPU model needed) are held to them.  Bars (bf16 ulp of the largest logit; max / mean over the row): what two
+# correct bf16 evaluations of a model this deep differ by -- the oracle-vs-reference distance measured when the goldens were
+# generated (tests/golden/make_golden.py, round 4, quoted per case below as max / mean for the early steps and the late step)
+# sets the bar: max(8 / 1.3, 2 x that), for the oracle AND for the HIP path.
+FULL_DEPTH_CASES = {
+    "gptxxl_c3": dict(registry="GPT-XXL", kwargs=dict(vocab_size=16384, block_size=576, num_classes=1000, cls_token_num=1,
+                                                      model_type="c2i"), wseed=31, lin_std=0.02, batch=2, cfg_scale=4.0, early=2,
+                      late=[575], rseed=41, layers=48, bar_early=(16.0, 2.8), bar_late=(32.0, 5.3)),   # oracle: 7.9 / 1.39, 15.8 / 2.60
+    "gpt3b_c4": dict(registry="GPT-3B", kwargs=dict(vocab_size=16384, block_size=576, num_classes=1000, cls_token_num=1,
+                                                    model_type="c2i"), wseed=31, lin_std=0.02, batch=2, cfg_scale=4.0, early=2,
+                     late=[420], rseed=42, layers=24, bar_early=(16.0, 3.2), bar_late=(21.0, 4.0)),    # oracle: 7.8 / 1.56, 10.1 / 1.98
+    "gptxl_t2i_c5": dict(registry="GPT-XL", kwargs=dict(vocab_size=16384, block_size=1024, cls_token_num=120, caption_dim=2048,
+                                                        model_type="t2i"), wseed=31, lin_std=0.02, batch=2, cfg_scale=7.5, early=2,
+                         late=[1142], rseed=43, layers=36, bar_early=(10.0, 1.9), bar_late=(23.0, 4.3)),   # oracle: 4.8 / 0.91, 11.3 / 2.11
+}
+
+
+def full_depth_inputs(case):
+    """(cond, emb_masks or None, steps) of a FULL_DEPTH case; steps = [(label, tokens [B, 1] or None, input_pos)]: the prefill over
+    positions 0..T-1, `early` decode positions T, T+1, ..., then the late positions (their caches come from cache_fill)."""
+    kw = case["kwargs"]
+    B, T, V = case["batch"], kw["cls_token_num"], kw["vocab_size"]
+    g = torch.Generator().manual_seed(case["rseed"])
+    if kw["model_type"] == "c2i":
+        cond, mask = torch.randint(0, kw["num_classes"], (B,), generator=g), None
+    else:
+        emb = torch.randn(B, T, kw["caption_dim"], generator=g)
+        lens = torch.randint(5, T + 1, (B,), generator=g)
+        mask = torch.zeros(B, T, dtype=torch.int64)
+        for b in range(B):
+            mask[b, T - int(lens[b]):] = 1
+        cond = (emb * mask[:, :, None]).to(torch.bfloat16).float()
+    steps = [("prefill", None, torch.arange(0, T))]
+    for i in range(case["early"]):
+        steps.append((f"pos{T + i}", torch.randint(0, V, (B, 1), generator=g), torch.tensor([T + i])))
+    for p in case["late"]:
+        steps.append((f"late{p}", torch.randint(0, V, (B, 1), generator=g), torch.tensor([p])))
+    return cond, mask, steps
+
+
+def cache_fill(B2, H, S, hd, pos, layer, dt, seed):
+    """Pseudo-random storage-dtype K/V for cache slots [0, pos) of one layer: ONE random draw per (seed), rolled along the slot
+    axis by a layer-dependent shift (the recipe tests/test_gpu_headline.py::_fill_caches uses)."""
+    g = torch.Generator().manual_seed(seed)
+    kb = (torch.randn(B2, H, S, hd, generator=g) * 0.6).to(dt)
+    vb = (torch.randn(B2, H, S, hd, generator=g) * 0.6).to(dt)
+    sh = (layer * 37) % S
+    return torch.roll(kb, sh, dims=2)[:, :, :pos], torch.roll(vb, sh, dims=2)[:, :, :pos]

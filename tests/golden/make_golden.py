@@ -29,7 +29,7 @@ from autoregressive.models.gpt import ModelArgs as RefArgs, Transformer as RefTr
 from tokenizer.tokenizer_image.vq_model import VQ_models as RefVQ  # noqa: E402
 
 from llamagen_amd.testing import synth_for_module  # noqa: E402
-from tests.cases import GPT_CASES, VQ_CASES, make_gpt_inputs, make_vq_inputs  # noqa: E402
+from tests.cases import FULL_DEPTH_CASES, GPT_CASES, VQ_CASES, cache_fill, full_depth_inputs, make_gpt_inputs, make_vq_inputs  # noqa: E402
 
 torch.set_grad_enabled(False)
 
@@ -71,6 +71,48 @@ def run_gpt_case(name, case):
             "trace_logits": np.stack([trace[s].numpy() for s in steps]).astype(np.float32)}
     np.savez_compressed(os.path.join(HERE, f"gpt_{name}.npz"), **arrs)
     print(f"gpt_{name}: tokens {out.shape} first row {out[0, :8].tolist()}")
+
+
+def run_full_depth_case(name, case):
+    """BASELINE configs[2..4] at full depth on the REFERENCE Transformer (bf16, CPU): teacher-forced CFG-mixed logits of the
+    prefill, the early positions and the late positions (K/V caches injected through the reference's own KVCache buffers)."""
+    kw = case["kwargs"]
+    m = build_ref_gpt(dict(case, dtype="bf16"))
+    assert len(m.layers) == case["layers"]
+    dt = torch.bfloat16
+    cond, emb_masks, steps = full_depth_inputs(case)
+    B, T = case["batch"], kw["cls_token_num"]
+    N = kw["block_size"]
+    if kw["model_type"] == "c2i":
+        cond_c = torch.cat([cond, torch.ones_like(cond) * m.num_classes])                       # generate.py:129-131
+    else:
+        cond_c = torch.cat([cond.to(dt), torch.zeros_like(cond).to(dt) + m.cls_embedding.uncond_embedding])   # generate.py:136-138
+    with torch.device("cpu"):
+        m.setup_caches(max_batch_size=2 * B, max_seq_length=T + N, dtype=dt)                      # generate.py:147-152
+    if emb_masks is not None:                                                                    # generate.py:154-163
+        em = torch.cat([emb_masks, emb_masks])
+        m.causal_mask[:, :, :T] = m.causal_mask[:, :, :T] * em.unsqueeze(1).to(m.causal_mask.dtype)
+        eye = torch.eye(m.causal_mask.size(1), m.causal_mask.size(2))
+        m.causal_mask[:] = m.causal_mask * (1 - eye) + eye
+    out = {}
+    H, hd = m.config.n_head, m.config.dim // m.config.n_head
+    for label, tok, ipos in steps:
+        if label.startswith("late"):
+            p = int(ipos[0])
+            S = m.layers[0].attention.kv_cache.k_cache.shape[2]
+            for li, layer in enumerate(m.layers):
+                kf, vf = cache_fill(2 * B, H, S, hd, p, li, dt, seed=1000 + p)
+                layer.attention.kv_cache.k_cache[:, :, :p] = kf
+                layer.attention.kv_cache.v_cache[:, :, :p] = vf
+        if tok is None:
+            logits, _ = m(None, cond_c, ipos)
+        else:
+            logits, _ = m(torch.cat([tok, tok]), None, ipos)
+        lg = logits[:, -1].float()
+        c, u = torch.split(lg, B, dim=0)
+        out[label] = (u + (c - u) * case["cfg_scale"]).numpy().astype(np.float32)               # generate.py:79-84, 94-99
+        print(f"full_depth_{name}: {label} max |logit| {np.abs(out[label]).max():.3f}", flush=True)
+    np.savez_compressed(os.path.join(HERE, f"fulldepth_{name}.npz"), **out)
 
 
 def run_vq_case(name, case):
@@ -129,6 +171,10 @@ if __name__ == "__main__":
         if only and name not in only:
             continue
         run_vq_case(name, case)
+    for name, case in FULL_DEPTH_CASES.items():
+        if only and name not in only:
+            continue
+        run_full_depth_case(name, case)
     with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
         json.dump({"torch": torch.__version__, "reference": "FoundationVision/LlamaGen @ 2024_08_07",
-                   "gpt_cases": list(GPT_CASES), "vq_cases": list(VQ_CASES)}, f, indent=1)
+                   "gpt_cases": list(GPT_CASES), "vq_cases": list(VQ_CASES), "full_depth_cases": list(FULL_DEPTH_CASES)}, f, indent=1)

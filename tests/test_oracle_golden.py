@@ -5,7 +5,8 @@ import pytest
 import torch
 
 from oracle import llamagen_oracle as O
-from tests.cases import GPT_CASES, VQ_CASES, make_gpt_inputs, make_vq_inputs, noise_stream
+from tests.cases import (FULL_DEPTH_CASES, GPT_CASES, VQ_CASES, cache_fill, full_depth_inputs, make_gpt_inputs, make_vq_inputs,
+                         noise_stream)
 from tests.util import DT, build_gpt_holder, build_vq_holder, load_golden, oracle_cfg
 
 FP32_CASES = [k for k, c in GPT_CASES.items() if c["dtype"] == "fp32"]
@@ -146,3 +147,67 @@ def test_topp_tie_groups_match_reference_count():
         assert 0 < kt.numel() < ties.numel(), "the boundary must cut the tie group"
         assert torch.equal(kt, ties[: kt.numel()])  # lowest indices first
         assert bool(kept[l[r] > 1.0].all()) and not bool(kept[l[r] < 1.0].any())
+
+
+def full_depth_distances(got_by_label, gold):
+    """per step: (max, mean) distance in bf16 ulps of the largest reference logit"""
+    out = {}
+    for label, ref in gold.items():
+        ulp = np.abs(ref).max() * ULP["bf16"]
+        err = np.abs(got_by_label[label] - ref)
+        out[label] = (float(err.max() / ulp), float(err.mean() / ulp))
+    return out
+
+
+def oracle_full_depth(case):
+    """The FULL_DEPTH case on the oracle: {label: CFG-mixed logits [B, V]} (prefill, early positions, late positions on the
+    injected cache contents) -- the teacher-forced sequence tests/golden/make_golden.py ran on the reference."""
+    kw = case["kwargs"]
+    _, sd = build_gpt_holder(case)
+    cfgo = oracle_cfg(case)
+    dt = torch.bfloat16
+    o = O.GPTOracle(cfgo, sd, dt)
+    cond, emb_masks, steps = full_depth_inputs(case)
+    B, T, N = case["batch"], kw["cls_token_num"], kw["block_size"]
+    if cfgo.model_type == "c2i":
+        cond_c = torch.cat([cond, torch.ones_like(cond) * cfgo.num_classes])
+    else:
+        cond_c = torch.cat([cond, torch.zeros_like(cond) + sd["cls_embedding.uncond_embedding"]])
+    o.setup_caches(2 * B, T + N)
+    if emb_masks is not None:
+        em = torch.cat([emb_masks, emb_masks])
+        cm = o.causal_mask
+        cm[:, :, :T] = cm[:, :, :T] & (em.unsqueeze(1) != 0)
+        o.causal_mask = cm | torch.eye(cm.size(1), dtype=torch.bool)
+    out = {}
+    H, hd = cfgo.n_head, cfgo.head_dim
+    for label, tok, ipos in steps:
+        if label.startswith("late"):
+            p = int(ipos[0])
+            S = o.k_cache[0].shape[2]
+            for li in range(len(o.k_cache)):
+                kf, vf = cache_fill(2 * B, H, S, hd, p, li, dt, seed=1000 + p)
+                o.k_cache[li][:, :, :p] = kf.float()
+                o.v_cache[li][:, :, :p] = vf.float()
+        x = None if tok is None else torch.cat([tok, tok])
+        lg = o.forward(x, cond_c if tok is None else None, ipos)[:, -1]
+        out[label] = O.cfg_mix(lg, case["cfg_scale"]).numpy()
+    return out
+
+
+@pytest.mark.parametrize("name", list(FULL_DEPTH_CASES))
+def test_oracle_full_depth_configs_3_4_5_vs_reference(name):
+    """BASELINE configs[2..4] at FULL depth (GPT-XXL 48 layers, GPT-3B 24 with head_dim 100, GPT-XL t2i 36 with T = 120 and
+    emb_masks), bf16, two images: the oracle's CFG-mixed logits of the prefill, two early positions and one late position (K/V
+    caches injected) against the REFERENCE's (tests/golden/fulldepth_*.npz)."""
+    case = FULL_DEPTH_CASES[name]
+    gold = load_golden("fulldepth_" + name)
+    dist = full_depth_distances(oracle_full_depth(case), gold)
+    print(name, "oracle vs reference (bf16 ulp max / mean):", {k: (round(a, 2), round(b, 3)) for k, (a, b) in dist.items()})
+    check_full_depth(case, dist)
+
+
+def check_full_depth(case, dist):
+    for label, (emax, emean) in dist.items():
+        bmax, bmean = case["bar_late"] if label.startswith("late") else case["bar_early"]
+        assert emax <= bmax and emean <= bmean, (label, emax, emean, bmax, bmean)

@@ -1,11 +1,12 @@
-"""rocprofv3 counter_collection.csv (FETCH_SIZE pass, WRITE_SIZE pass of tools/pmc_target.py) -> profiles/r03_pmc.json and a
-readable profiles/r03_pmc.csv.  FETCH_SIZE is in KB and counts HALF of a wide coalesced read stream on gfx950
+"""rocprofv3 counter_collection.csv (FETCH_SIZE pass, WRITE_SIZE pass of tools/pmc_target.py) -> profiles/<TAG>_pmc.json and a
+readable profiles/<TAG>_pmc.csv (TAG = LGEN_PMC_TAG, default r04).  FETCH_SIZE is in KB and counts HALF of a wide coalesced read stream on gfx950
 (MI355X_MICROARCH.md, HBM section): bytes = KB * 1024 * 2; WRITE_SIZE: bytes = KB * 1024."""
 import csv, glob, json, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 d, H, hd, F, V = 1024, 16, 64, 2816, 16384
-B2 = 2 * int(os.environ.get("LGEN_PMC_B", "128"))  # rows of the decode chain (tools/pmc_target.py)
+B2 = 2 * int(os.environ.get("LGEN_PMC_B", "320"))  # rows of the decode chain (tools/pmc_target.py)
+TAG = os.environ.get("LGEN_PMC_TAG", "r04")
 GEMM = {  # kernel-name fragment -> (bench key, algorithmic weight bytes)
     "EPI_QKV": ("wqkv", 3 * d * d * 2), "5, 4>(GemmArgs)": ("wqkv", 3 * d * d * 2),
 }
@@ -20,12 +21,12 @@ def rows(pattern):
 
 def classify(name, grid):
     """decode-chain kernel -> (key, algorithmic bytes read) for GPT-L."""
-    if "attn_decode_kernel" in name:
+    if "attn_decode" in name:   # attn_decode_kernel / attn_decode_persist_kernel
         return "attn", None
-    if "gemm_normpre_kernel" in name or "gemm_kernel" in name:
-        # template args: <D, MT, NT, EPI, ...>; EPI 5 = QKV, 4 = SWIGLU, 0 = ROWS, 3 = RES
+    if "gemm_normpre_kernel" in name or "gemm_kernel" in name or "gemm_steady_kernel" in name or "gemm_tile_kernel" in name:
+        # template args: skinny <D, MT, NT, EPI, ...>, tile <D, WM, WN, MTV, NTV, KB, STAGES, EPI, NORM, LW>; EPI 5 = QKV, 4 = SWIGLU, 0 = ROWS, 3 = RES
         args = name[name.index("<") + 1:name.index(">")].split(",")
-        epi = int(args[3])
+        epi = int(args[7 if "gemm_tile_kernel" in name else 3])
         if epi == 5:
             return "wqkv", 3 * d * d * 2
         if epi == 4:
@@ -38,7 +39,7 @@ def classify(name, grid):
 
 
 def main(fetch_dir, write_dir):
-    res = {"gemm": {"source": "profiles/r03_pmc.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/pmc_target.py)"}}
+    res = {"gemm": {"source": f"profiles/{TAG}_pmc.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/pmc_target.py)"}}
     table = []
     for counter, ddir, scale in (("FETCH_SIZE", fetch_dir, 2048.0), ("WRITE_SIZE", write_dir, 1024.0)):
         acc = {}
@@ -92,8 +93,8 @@ def main(fetch_dir, write_dir):
     res.setdefault("attn_decode_kernel", {})["source"] = res["gemm"]["source"]
     res["rows"] = B2
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
-    json.dump(res, open(os.path.join(ROOT, "profiles", "r03_pmc.json"), "w"), indent=1)
-    with open(os.path.join(ROOT, "profiles", "r03_pmc.csv"), "w") as f:
+    json.dump(res, open(os.path.join(ROOT, "profiles", f"{TAG}_pmc.json"), "w"), indent=1)
+    with open(os.path.join(ROOT, "profiles", f"{TAG}_pmc.csv"), "w") as f:
         f.write(f"# rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separate pass, WRITE_SIZE) -- python tools/pmc_target.py ; GPT-L bf16, B2 = {B2}\n")
         f.write("# FETCH_SIZE KB x 1024 x 2 (gfx950 correction for wide coalesced reads, MI355X_MICROARCH.md); WRITE_SIZE KB x 1024\n")
         f.write("counter,kernel,launches,bytes_per_launch,algorithmic_bytes,ratio\n")

@@ -1,9 +1,9 @@
 """Workload for the PMC passes of the round (run under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and, in a SEPARATE
-pass, `--pmc WRITE_SIZE`): (1) a short GPT-L bf16 cfg-4 generate() of LGEN_PMC_B images (default 128 = the bench's four batches
-per chain, 256 rows; the decode-chain GEMM kernels with the bench's tile shapes; 40 tokens keep the serialized,
+pass, `--pmc WRITE_SIZE`): (1) a short GPT-L bf16 cfg-4 generate() of LGEN_PMC_B images (default 320 = the bench's ten batches
+per chain, 640 rows; the decode-chain GEMM kernels with the bench's tile shapes; 40 tokens keep the serialized,
 counter-instrumented run short), (2) the decode attention at cache positions
 63 / 287 / 575 on full-size KV slabs, one launch per layer.  tools/pmc_summary.py turns the two outputs into
-profiles/r03_pmc.json, which bench.py quotes as `traffic`."""
+profiles/r04_pmc.json, which bench.py quotes as `traffic`."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,7 +11,7 @@ from llamagen_amd import GPT_models, generate
 from llamagen_amd import _lib as L
 
 dev = torch.device("cuda:0")
-N, B = 576, int(os.environ.get("LGEN_PMC_B", "128"))
+N, B = 576, int(os.environ.get("LGEN_PMC_B", "320"))
 torch.manual_seed(0)
 m = GPT_models["GPT-L"](vocab_size=16384, block_size=N, num_classes=1000, cls_token_num=1, model_type="c2i")
 torch.nn.init.normal_(m.output.weight, 0, 0.02)

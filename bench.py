@@ -47,10 +47,52 @@ CONFIGS = {
     5: dict(name="LlamaGen-XL t2i stage2 512px", gpt="GPT-XL", params="775M", img=512, batch=16, cfg=7.5, top_k=1000, model_type="t2i",
             T=120, vq_gflop=1021.6),
 }
+GPT_DIMS = {"GPT-B": (12, 12, 768), "GPT-L": (24, 16, 1024), "GPT-XL": (36, 20, 1280), "GPT-XXL": (48, 24, 1536),
+            "GPT-3B": (24, 32, 3200)}   # (layers, heads, dim) of the registry sizes (gpt.py:438-461): the KV budget needs no model
 GPT_NAME, IMG, BATCH, CFG, TOPK = "GPT-L", 384, 32, 4.0, 2000   # config 2 (the headline)
 LAT = IMG // 16
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured copy)
 CAPTION_DIM = 2048     # T5-XL feature width (gpt.py:40)
+
+
+def plan_schedule(args, B, N, T):
+    """Batches per decode chain and chains in flight (sets args.lanes) for this run, and the per-chain HBM need; raises SystemExit
+    when the schedule does not fit the per-GPU budget -- BEFORE anything is allocated (needs no device and no model)."""
+    # Schedule (round 4).  Config 2: TWO decode chains in flight, each carrying half of the run's steps (batches of 32) -- up to 12,
+    # i.e. up to 768 rows with CFG.  Measured on MI355X (gpurun_out/ab2.log, attn_ab3/4.log; img/s, tile GEMMs + persistent
+    # attention): 4 x 3 chains 107-110, 8 x 3 116, 8 x 2 119-120, 16 x 2 120, 16 x 1 107 -- per image the GEMM cost falls with the rows
+    # of a chain (weights and launch chain amortised: 6.2 / 4.4 / 3.7 us per image-step at 256 / 512 / 1024 rows), attention and the
+    # decoder do not care, and two wide chains overlap better than three narrow ones.  Every batch still is its own generate() (own
+    # labels, own Exp(1) draws in the reference's order, rows never interact before the sampler).  Other configs: as in round 3.
+    if args.batches_per_chain > 0:
+        bpc = args.batches_per_chain
+    elif args.config == 2:
+        bpc = max(1, min(12, (args.steps + 1) // 2))   # <= 768 rows: the tile shapes tests/test_gpu_headline.py holds to the oracle
+    else:
+        bpc = {3: 4, 4: 2, 5: 4}[args.config]
+    chains = (args.steps + bpc - 1) // bpc
+    n_layer, n_head, dim = GPT_DIMS[CONFIGS[args.config]["gpt"]]
+    hdp = 64 if dim // n_head <= 64 else 128
+    per_chain = (n_layer * 2 * B * bpc * n_head * (T + N + 8) * hdp * 2 * 2      # K and V slabs, CFG rows
+                 + N * B * bpc * 16384 * 4)                                       # Exp(1) noise
+    if args.lanes <= 0:
+        if args.config == 2:
+            args.lanes = min(2, chains)
+        else:
+            # k chains in flight take ~T_k (round 3, 256-row chains with the decoder in 32-image pieces: 1, 1.71, 2.49 -- tools/exp_r3c.py);
+            # a run of C chains on L lanes costs floor(C/L) * T_L + T_(C mod L): use the cheapest L
+            Tk = {0: 0.0, 1: 1.0, 2: 1.44, 3: 2.02} if bpc == 1 else ({0: 0.0, 1: 1.0, 2: 1.5, 3: 2.1} if bpc < 4 else
+                                                                       {0: 0.0, 1: 1.0, 2: 1.71, 3: 2.49})
+            args.lanes = min((1, 2, 3), key=lambda l: (chains // l) * Tk[l] + Tk[chains % l])
+        # KV slabs + noise of the chains in flight must fit the 288 GB of HBM3E with room for weights and decoder activations
+        while args.lanes > 1 and args.lanes * per_chain > HBM_BUDGET_BYTES:
+            args.lanes -= 1
+    # per-rank HBM budget (the one-chain transparency leg needs one more chain's worth)
+    need = (args.lanes + (0 if (args.no_one_chain or args.lanes == 1) else 1)) * per_chain
+    if need > HBM_BUDGET_BYTES + 60e9:
+        raise SystemExit(f"schedule needs {need / 1e9:.0f} GB of KV slabs + noise per GPU ({args.lanes} chains x {bpc} batches of {B}): "
+                         f"over the {HBM_BUDGET_BYTES / 1e9:.0f} GB budget; lower --batches-per-chain or --lanes")
+    return bpc, per_chain
 
 
 def build_models(dev, weight_seed=0, config=2):
@@ -275,12 +317,17 @@ def cpu_config1(threads):
             idx = O.generate(model, torch.tensor([207]), N, cfg_scale=1.0, cfg_interval=-1, temperature=1.0, top_k=TOPK, top_p=1.0,
                              sample_logits=True)
             return O.vq_decode_code(vsd, idx, [1, 8, 16, 16])
-    t0 = time.time()
-    img = run()
-    sec = time.time() - t0
+    run()  # warm-up (allocator, thread pool, first-touch of the weights)
+    secs = []
+    for _ in range(2):
+        t0 = time.time()
+        img = run()
+        secs.append(time.time() - t0)
+    sec = min(secs)
     assert tuple(img.shape) == (1, 3, 256, 256)
-    return {"value": round(1.0 / sec, 4), "unit": "images/s", "seconds": round(sec, 2), "kind": kind, "threads": threads,
-            "workload": "LlamaGen-B 256px c2i, 1 image, cfg 1.0, fp32, top-k 2000, generate + decode_code, timed in full (one cold run)"}
+    return {"value": round(1.0 / sec, 4), "unit": "images/s", "seconds": round(sec, 2), "seconds_all": [round(x, 2) for x in secs],
+            "kind": kind, "threads": threads,
+            "workload": "LlamaGen-B 256px c2i, 1 image, cfg 1.0, fp32, top-k 2000, generate + decode_code, timed in full (min of 2 after a warm-up run)"}
 
 
 def cpu_baseline(steps=16, budget_s=30.0, with_c1=True):
@@ -338,6 +385,16 @@ def cpu_baseline(steps=16, budget_s=30.0, with_c1=True):
                      f"+ 32 x the VQ decode time of one 384 px image ({t_vq:.2f} s, measured on 2)"}
     if with_c1:
         out["c1"] = cpu_config1(best_thr)
+    if kind == "port":
+        # same-host calibration of the port against the reference's own modules (tools/cpu_calibrate.py, run in the build container
+        # where /root/reference exists): how much faster / slower the port is than the reference on the same slice
+        try:
+            cal = json.load(open(os.path.join(ROOT, "profiles", "r04_cpu_ref_vs_port.json")))
+            out["port_over_reference"] = {"slice_images_per_s": cal["port_over_reference"]["slice"], "c1_images_per_s": cal["port_over_reference"]["c1"],
+                                          "source": "profiles/r04_cpu_ref_vs_port.json (both run back to back in the build container, same threads)"}
+            out["c1"]["port_over_reference"] = cal["port_over_reference"]["c1"]
+        except Exception:  # noqa: BLE001
+            out["port_over_reference"] = None
     return out
 
 
@@ -423,7 +480,7 @@ def standin_main(args, rank, local, world, rccl_ranks):
                           "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "bf16", "rccl_ranks": rccl_ranks,
                           "data": "STAND-IN device step on CPU/gloo (launch-path test, NOT a measurement)",
-                          "config": {"workload": "stand-in", "parallelism": f"dp{world}"}}), flush=True)
+                          "config": {"workload": "stand-in", "parallelism": f"dp{world}", "global_batch": BATCH * world}}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -446,11 +503,18 @@ def main():
     ap.add_argument("--no-live-traffic", action="store_true", help="quote the committed PMC pass instead of running rocprofv3 --pmc now")
     ap.add_argument("--no-solo", action="store_true", help="skip the extra one-generate()-at-a-time leg (keeps a "
                                                            "rocprofv3 kernel average of this run to the timed chain shape)")
+    ap.add_argument("--budget-check-only", action="store_true", help="plan the schedule, check the per-GPU HBM budget, print it, exit")
     ap.add_argument("--allow-untested-schedule", action="store_true", help="run a GEMM schedule no end-to-end parity test names")
     ap.add_argument("--no-one-chain", action="store_true", help="skip the extra one-chain-in-flight leg (it needs another chain's KV slabs)")
     ap.add_argument("--standin", action="store_true", help=argparse.SUPPRESS)  # CPU/gloo test of the launch path, see standin_main
     args = ap.parse_args()
 
+    if args.budget_check_only:   # no device, no model: the plan and its HBM need
+        C0 = CONFIGS[args.config]
+        bpc0, per0 = plan_schedule(args, C0["batch"], (C0["img"] // 16) ** 2, C0["T"])
+        print(json.dumps({"config": args.config, "batches_per_chain": bpc0, "chains_in_flight_per_gpu": args.lanes,
+                          "kv_plus_noise_GB_per_chain": round(per0 / 1e9, 1), "budget_GB": HBM_BUDGET_BYTES / 1e9}))
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:  # plain `python bench.py --gpus N`: become the launcher
         if not args.standin and torch.cuda.device_count() < args.gpus:
             raise SystemExit(f"--gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) are visible")
@@ -492,40 +556,7 @@ def main():
         lens = torch.randint(5, T + 1, (B,), generator=g)
         emb_masks = (torch.arange(T).unsqueeze(0) >= (T - lens).unsqueeze(1)).to(torch.int64).to(dev)
         skw["emb_masks"] = emb_masks
-    # Schedule (round 4).  Config 2: TWO decode chains in flight, each carrying half of the run's steps (batches of 32) -- up to 16,
-    # i.e. up to 1024 rows with CFG.  Measured on MI355X (gpurun_out/ab2.log, attn_ab3/4.log; img/s, tile GEMMs + persistent
-    # attention): 4 x 3 chains 107-110, 8 x 3 116, 8 x 2 119-120, 16 x 2 120, 16 x 1 107 -- per image the GEMM cost falls with the rows
-    # of a chain (weights and launch chain amortised: 6.2 / 4.4 / 3.7 us per image-step at 256 / 512 / 1024 rows), attention and the
-    # decoder do not care, and two wide chains overlap better than three narrow ones.  Every batch still is its own generate() (own
-    # labels, own Exp(1) draws in the reference's order, rows never interact before the sampler).  Other configs: as in round 3.
-    if args.batches_per_chain > 0:
-        bpc = args.batches_per_chain
-    elif args.config == 2:
-        bpc = max(1, min(12, (args.steps + 1) // 2))   # <= 768 rows: the tile shapes tests/test_gpu_headline.py holds to the oracle
-    else:
-        bpc = {3: 4, 4: 2, 5: 4}[args.config]
-    chains = (args.steps + bpc - 1) // bpc
-    cfg_m = gpt.config
-    hdp = 64 if cfg_m.dim // cfg_m.n_head <= 64 else 128
-    per_chain = (cfg_m.n_layer * 2 * B * bpc * cfg_m.n_head * (T + N + 8) * hdp * 2 * 2      # K and V slabs, CFG rows
-                 + N * B * bpc * cfg_m.vocab_size * 4)                                        # Exp(1) noise
-    if args.lanes <= 0:
-        if args.config == 2:
-            args.lanes = min(2, chains)
-        else:
-            # k chains in flight take ~T_k (round 3, 256-row chains with the decoder in 32-image pieces: 1, 1.71, 2.49 -- tools/exp_r3c.py);
-            # a run of C chains on L lanes costs floor(C/L) * T_L + T_(C mod L): use the cheapest L
-            Tk = {0: 0.0, 1: 1.0, 2: 1.44, 3: 2.02} if bpc == 1 else ({0: 0.0, 1: 1.0, 2: 1.5, 3: 2.1} if bpc < 4 else
-                                                                       {0: 0.0, 1: 1.0, 2: 1.71, 3: 2.49})
-            args.lanes = min((1, 2, 3), key=lambda l: (chains // l) * Tk[l] + Tk[chains % l])
-        # KV slabs + noise of the chains in flight must fit the 288 GB of HBM3E with room for weights and decoder activations
-        while args.lanes > 1 and args.lanes * per_chain > HBM_BUDGET_BYTES:
-            args.lanes -= 1
-    # per-rank HBM budget, checked BEFORE anything is allocated (the one-chain transparency leg below needs one more chain's worth)
-    need = (args.lanes + (0 if (args.no_one_chain or args.lanes == 1) else 1)) * per_chain
-    if need > HBM_BUDGET_BYTES + 60e9:
-        raise SystemExit(f"schedule needs {need / 1e9:.0f} GB of KV slabs + noise per GPU ({args.lanes} chains x {bpc} batches of {B}): "
-                         f"over the {HBM_BUDGET_BYTES / 1e9:.0f} GB budget; lower --batches-per-chain or --lanes")
+    bpc, per_chain = plan_schedule(args, B, N, T)
     pipe = SamplingPipeline(gpt, vq, lanes=args.lanes, steps_per_turn=args.steps_per_turn, vq_low_priority=args.vq_own_stream,
                             batches_per_chain=bpc,
                             vq_chunk=B if (bpc > 1 and args.lanes > 1) else 0)  # decode_code() batch by batch: finer interleaving

@@ -56,6 +56,30 @@ def test_bench_gpus_2_launches_its_own_ranks_on_gloo():
     assert j["config"]["parallelism"] == "dp2" and "STAND-IN" in j["data"] and j["value"] > 0
 
 
+def test_bench_gpus_8_standin_eight_ranks_gather_in_the_reference_order():
+    """The 8-GPU shape of BASELINE configs[2] without the hardware: `python bench.py --gpus 8 --standin` spawns EIGHT gloo ranks,
+    every step ends in one gather to rank 0, rank 0 prints one line for the whole job (value = all ranks' images / max-over-ranks
+    time)."""
+    r = _run_bench(["--gpus", "8", "--steps", "2", "--warmup", "1", "--standin"], timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["rccl_ranks"] == 8 and j["config"]["parallelism"] == "dp8" and j["scaling"] == "weak"
+    assert j["config"]["global_batch"] == 8 * 32 and j["value"] > 0
+
+
+def test_hbm_budget_is_checked_before_allocation():
+    """bench.py refuses a schedule whose KV slabs + noise exceed the per-GPU budget BEFORE anything is allocated: GPT-XXL
+    (config 3) with 3 chains of 16 batches would need 3 x 16 x (10.6 GB of KV + 1.2 GB of noise)."""
+    r = _run_bench(["--config", "3", "--lanes", "3", "--batches-per-chain", "16", "--steps", "48", "--budget-check-only"], timeout=300)
+    assert r.returncode != 0 and "budget" in (r.stderr + r.stdout)
+    r = _run_bench(["--config", "2", "--steps", "20", "--budget-check-only"], timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert j["batches_per_chain"] == 10 and j["chains_in_flight_per_gpu"] == 2 and j["kv_plus_noise_GB_per_chain"] < 60
+
+
 def test_bench_torchrun_form_and_world_mismatch():
     """The driver's torchrun form keeps working (WORLD_SIZE set -> no self-launch), and a WORLD_SIZE that disagrees with --gpus
     is refused."""

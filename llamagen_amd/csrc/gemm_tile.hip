@@ -208,9 +208,15 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_tile_kernel(GemmArgs
     };
 
     // ---- NORM prologue requests: norm weight (shared, every consumer writes the same bytes) + this wave's row statistics ----
+    // row statistics staging: the last ring slot (idle until stage STAGES-1 is issued) when a wave's share fits there, else a
+    // dedicated region behind the norm weight (launcher: a.passes = 1 selects the slot, 2 the dedicated region)
     unsigned char* s_nw = smem + STAGES * STAGE_B;
-    unsigned char* s_ssq = smem + (STAGES - 1) * STAGE_B + cw * (STAGE_B / NC);  // the last slot is idle until stage STAGES-1 is issued
-    const int q4 = a.parts >> 2;  // float4s per statistics row (launcher: parts % 4 == 0, MTV * 16 * parts * 4 <= STAGE_B / NC)
+    const int nw_bytes = (a.KCH * D::KC * D::ESZ + 1023) / 1024 * 1024;
+    const int ssq_share = MTV * 16 * a.parts * 4;
+    const unsigned ssq_off = a.passes == 2 ? (unsigned)(STAGES * STAGE_B + nw_bytes + cw * ssq_share)
+                                           : (unsigned)((STAGES - 1) * STAGE_B + cw * (STAGE_B / NC));
+    unsigned char* s_ssq = smem + ssq_off;
+    const int q4 = a.parts >> 2;  // float4s per statistics row (launcher: parts % 4 == 0)
     if constexpr (NORM) {
         const int nwb = a.KCH * D::KC * D::ESZ;  // bytes of the norm weight
         for (int o = 0; o < nwb; o += 1024) {
@@ -234,10 +240,14 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_tile_kernel(GemmArgs
     // ---- RMSNorm row scales, fixed summation order of gemm_normpre.hip / ssq_rows_now (bit-identical) ----
     float ri[MTV];
     if constexpr (NORM) {
+        if (a.db & 16) {   // ablation: no statistics prologue
+#pragma unroll
+            for (int i = 0; i < MTV; ++i) ri[i] = 1.0f;
+        } else {
         if constexpr (LW == 0) gt_wait_vm<(STAGES - 1) * P>();   // the prologue pieces are older than every stage piece
         else gt_wait_vm<0>();
         const int r = lane & 15, g = lane >> 4;
-        const unsigned ssq0 = lds0 + (STAGES - 1) * STAGE_B + cw * (STAGE_B / NC);
+        const unsigned ssq0 = lds0 + ssq_off;
 #pragma unroll
         for (int i = 0; i < MTV; ++i) {
             const unsigned rowa = ssq0 + (unsigned)((i * 16 + r) * a.parts) * 4;
@@ -266,6 +276,7 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_tile_kernel(GemmArgs
             s += __shfl_xor(s, 16, 64);
             s += __shfl_xor(s, 32, 64);
             ri[i] = 1.0f / sqrtf(s * a.inv_k + a.eps);
+        }
         }
     }
 
@@ -325,6 +336,7 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_tile_kernel(GemmArgs
         slot = slot + 1 == STAGES ? 0 : slot + 1;
     }
 
+    if (a.db & 8) return;   // ablation: no epilogue
     // ---- epilogue: this wave's NTV x MTV tiles ----
     if constexpr (EPI == EPI_QKV) {
         QkvCol qc;
@@ -362,8 +374,19 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_tile_kernel(GemmArgs
         for (int j = 0; j < NTV; j += 2) {
             if (ntw0 + j < ntiles) {
 #pragma unroll
-                for (int i = 0; i < MTV; ++i)
-                    epilogue<D, EPI>(a, ntw0 + j, mtw0 + i, lane, acc[j][i], acc[j + 1][i], make_uint4(0, 0, 0, 0), 0);
+                for (int i = 0; i < MTV; ++i) {
+                    // silu(w1 x) * (w3 x) with the hardware exp / reciprocal (v_exp_f32, v_rcp_f32: ~1e-7 relative, far below the
+                    // 2^-9 half-ulp of the bf16 rounding that follows; the IEEE expf + division of the skinny kernels' epilogue
+                    // cost ~30 VALU instructions per element: 3.3 of the 8 us this kernel spends outside its K loop at 640 rows)
+                    const f32x4_t v = acc[j][i], v2 = acc[j + 1][i];
+                    float o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x = D::rnd(v[e]), y = D::rnd(v2[e]);
+                        o[e] = D::rnd(x * __frcp_rn(1.0f + __expf(-x))) * y;
+                    }
+                    D::st4(a.out, D::xp_off(((ntw0 + j) >> 1) * 16 + (lane >> 4) * 4, mtw0 + i, lane & 15, a.MTs), o[0], o[1], o[2], o[3]);
+                }
             }
         }
     } else {
@@ -383,13 +406,20 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_tile_kernel(GemmArgs
 
 // ---- launch table ---------------------------------------------------------------------------------------------------------
 template <typename D, int WM, int WN, int MTV, int NTV, int KB, int STAGES, int EPI, bool NORM, int LW>
-static int gt_launch(const GemmArgs& a, hipStream_t st) {
+static int gt_launch(const GemmArgs& a_in, hipStream_t st) {
+    GemmArgs a = a_in;
     constexpr int NW = WM * WN, MTW = WM * MTV, NTW = WN * NTV, CPS = KB * (MTW + NTW), STAGE_B = CPS * 1024;
     if (a.MTs % MTW || a.KCH % KB || a.KCH / KB < STAGES - 1) return LGEN_ERR_UNSUPPORTED;
     size_t lds = (size_t)STAGES * STAGE_B;
+    a.passes = 1;
     if (NORM) {
-        if (a.parts % 4 || (size_t)MTV * 16 * a.parts * 4 > (size_t)STAGE_B / NW) return LGEN_ERR_UNSUPPORTED;
+        if (a.parts % 4) return LGEN_ERR_UNSUPPORTED;
         lds += ((size_t)a.KCH * D::KC * D::ESZ + 1023) / 1024 * 1024;
+        const size_t share = (size_t)MTV * 16 * a.parts * 4;
+        if (share > (size_t)STAGE_B / NW) {   // the statistics do not fit the idle ring slot: a region of their own
+            a.passes = 2;
+            lds += share * NW;
+        }
     }
     if (lds > 160 * 1024) return LGEN_ERR_UNSUPPORTED;
     const int ntiles = a.N / 16;
@@ -407,7 +437,8 @@ static int gt_launch(const GemmArgs& a, hipStream_t st) {
 // shapes (WM, WN, MTV, NTV, KB, STAGES, LW) with an instantiation; X(...) is expanded per (EPI, NORM) below
 #define GT_SHAPES_NORM(X)                                                                                        \
     X(4, 1, 1, 3, 4, 4, 4) X(4, 1, 1, 4, 4, 4, 4) X(4, 1, 1, 6, 2, 4, 4) X(4, 1, 1, 6, 4, 3, 4) X(4, 1, 1, 8, 2, 4, 4) \
-    X(4, 1, 2, 4, 2, 4, 4) X(4, 1, 2, 6, 2, 4, 4) X(4, 1, 2, 8, 2, 4, 4) X(4, 1, 1, 2, 4, 4, 4) X(4, 1, 1, 3, 4, 4, 0)
+    X(4, 1, 2, 4, 2, 4, 4) X(4, 1, 2, 6, 2, 4, 4) X(4, 1, 2, 8, 2, 4, 4) X(4, 1, 1, 2, 4, 4, 4) X(4, 1, 1, 3, 4, 4, 0) \
+    X(8, 1, 1, 8, 2, 4, 4) X(8, 1, 1, 6, 2, 4, 4) X(8, 1, 1, 4, 2, 4, 4)
 #define GT_SHAPES_PLAIN(X)                                                                                       \
     X(2, 2, 1, 1, 4, 4, 4) X(2, 2, 1, 2, 4, 4, 4) X(2, 2, 2, 1, 4, 4, 4) X(2, 2, 2, 2, 4, 4, 4) X(2, 2, 2, 2, 2, 4, 4) \
     X(4, 1, 1, 2, 4, 4, 4) X(2, 2, 1, 1, 4, 4, 0) X(2, 2, 4, 1, 4, 4, 4) X(2, 2, 4, 2, 2, 4, 4)
@@ -416,7 +447,8 @@ template <typename D, int EPI, bool NORM>
 static int gt_dispatch(const GemmArgs& a, int wm, int wn, int mtv, int ntv, int kb, int stages, int lw, hipStream_t st) {
 #define GT_CASE(WM_, WN_, MTV_, NTV_, KB_, ST_, LW_)                                                                 \
     if (wm == WM_ && wn == WN_ && mtv == MTV_ && ntv == NTV_ && kb == KB_ && stages == ST_ && lw == LW_) {            \
-        if constexpr (EPI == EPI_SWIGLU && (NTV_ % 2)) return LGEN_ERR_UNSUPPORTED;                                   \
+        if constexpr ((EPI == EPI_SWIGLU && (NTV_ % 2)) || (EPI == EPI_QKV && WM_ * WN_ == 8 && NTV_ == 8)) /* (spills at 168 VGPRs) */ \
+            return LGEN_ERR_UNSUPPORTED;                                                                              \
         else return gt_launch<D, WM_, WN_, MTV_, NTV_, KB_, ST_, EPI, NORM, LW_>(a, st);                               \
     }
     if constexpr (NORM) {
@@ -428,7 +460,7 @@ static int gt_dispatch(const GemmArgs& a, int wm, int wn, int mtv, int ntv, int 
     return LGEN_ERR_UNSUPPORTED;
 }
 
-static int gt_ablate() {   // development switch: bit 0 no RMSNorm VALU work, bit 1 no LDS reads / MFMAs, bit 2 no operand DMA
+static int gt_ablate() {   // development switch: bit 0 no RMSNorm VALU work, bit 1 no LDS reads / MFMAs, bit 2 no operand DMA, bit 3 no epilogue, bit 4 no statistics prologue
     const char* e = getenv("LGEN_TILE_ABLATE");
     return e ? atoi(e) : 0;
 }

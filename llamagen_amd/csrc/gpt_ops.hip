@@ -511,7 +511,7 @@ __global__ __launch_bounds__(64 * NWV) void attn_decode_persist_kernel(AttnArgs 
 //   <= 128 rows (4.4 us at kv_len 1 vs 6.1 us with 4 waves, same 6.4 TB/s incremental rate); 3 = (4, 2); 4 = (2, 1); 5 = (4, 1);
 //   6 / 7 (round 3): (2, 2) with 2 / 4 heads of a row per workgroup (fewer workgroups to dispatch at >= 256 rows);
 //   8 .. 13 (round 4): the persistent form, (loads per buffer, waves per workgroup) = 8: (4, 8); 9: (4, 8) x two workgroups per CU;
-//   10: (4, 4); 11: (2, 8); 12: (2, 4); 13: (1, 8) -- one position for all rows only.
+//   10: (4, 4); 11: (2, 8); 12: (2, 4); 13: (1, 8); 14: (3, 4) -- one position for all rows only.
 // K/V loads are non-temporal (ldg_nt): every cache row is read once per step, and keeping 75-150 MB per layer out of the
 // memory-side cache leaves the (chain-shared) weights there: 26.5 vs 28.5 us at kv_len 576, 71.6 vs 68.6 img/s.  Fixed at
 // compile time: a per-load run-time choice costs the compiler its count of loads in flight (vmcnt(0) before every compute).
@@ -520,7 +520,7 @@ static int attn_decode_impl(const void* q, const void* k_cache, const void* v_ca
                             int n_head, int hd, int hdp, int S8, int kv_row_stride, int dtype, int variant_arg, void* stream) {
     AttnArgs a{q, k_cache, v_cache, out_packed, pos_ptr, pos_stride, mask, n_head, hd, hdp, S8, MTs, 0.f,
                kv_row_stride > 0 ? kv_row_stride : hdp, mask_len > 0 ? mask_len : S8};
-    if (variant_arg < -1 || variant_arg > 13) return LGEN_ERR_BAD_ARG;
+    if (variant_arg < -1 || variant_arg > 14) return LGEN_ERR_BAD_ARG;
     a.sf = sqrtf(1.0f / sqrtf((float)hd));
     hipStream_t st = (hipStream_t)stream;
     const int epl = dtype != LGEN_F32 ? 8 : 4;
@@ -548,8 +548,8 @@ static int attn_decode_impl(const void* q, const void* k_cache, const void* v_ca
             n_cu = v > 0 ? v : 256;
         }
         const int items = B2 * n_head;
-        const int nwv = (variant == 10 || variant == 12) ? 4 : 8;
-        const int ch = variant <= 10 ? 4 : (variant <= 12 ? 2 : 1);
+        const int nwv = (variant == 10 || variant == 12 || variant == 14) ? 4 : 8;
+        const int ch = variant == 14 ? 3 : (variant <= 10 ? 4 : (variant <= 12 ? 2 : 1));
         int wgs = n_cu * (variant == 9 ? 2 : 1);
         if (wgs * nwv > items) wgs = (items + nwv - 1) / nwv;
         const int total_waves = wgs * nwv;
@@ -557,6 +557,7 @@ static int attn_decode_impl(const void* q, const void* k_cache, const void* v_ca
         do {                                                                                                               \
             if (ch == 4 && nwv == 8) hipLaunchKernelGGL((attn_decode_persist_kernel<DT, L, 4, 8>), dim3(wgs), dim3(512), 0, st, a, items, total_waves); \
             else if (ch == 4) hipLaunchKernelGGL((attn_decode_persist_kernel<DT, L, 4, 4>), dim3(wgs), dim3(256), 0, st, a, items, total_waves);        \
+            else if (ch == 3) hipLaunchKernelGGL((attn_decode_persist_kernel<DT, L, 3, 4>), dim3(wgs), dim3(256), 0, st, a, items, total_waves);        \
             else if (ch == 2 && nwv == 8) hipLaunchKernelGGL((attn_decode_persist_kernel<DT, L, 2, 8>), dim3(wgs), dim3(512), 0, st, a, items, total_waves); \
             else if (ch == 2) hipLaunchKernelGGL((attn_decode_persist_kernel<DT, L, 2, 4>), dim3(wgs), dim3(256), 0, st, a, items, total_waves);        \
             else hipLaunchKernelGGL((attn_decode_persist_kernel<DT, L, 1, 8>), dim3(wgs), dim3(512), 0, st, a, items, total_waves);                     \

@@ -75,9 +75,11 @@ TILE_SCHEDULES = {
          "head": (4, 1, 2, 8, 2, 4, 4)},
     # 640 rows (`bench.py --steps 20`: two chains of ten batches), gpurun_out/tile_sweep4.log: a launch is whole ROUNDS of <= 256
     # workgroups, so the shapes are the ones that fill one round -- wqkv 240 workgroups 16.0 us (22.1 with the 512-row shape: 320
-    # workgroups = two rounds), wo 160 / 6.3 (8.1), w1||w3 220 / 19.2, w2 160 / 10.9 (14.6), lm_head 640 / 52.2
-    40: {"qkv": (4, 1, 1, 8, 2, 4, 4), "wo": (2, 2, 2, 2, 4, 4, 4), "w13": (4, 1, 2, 8, 2, 4, 4), "w2": (2, 2, 2, 2, 4, 4, 4),
-         "head": (4, 1, 2, 8, 2, 4, 4)},
+    # workgroups = two rounds), wo 160 / 6.3 (8.1), w1||w3 220 / 18.2, w2 160 / 10.9 (14.6), lm_head 640 / 50.3
+    # (w1||w3 and lm_head: eight consumer waves x one m-tile -- two per SIMD, one's RMSNorm VALU work under the other's MFMAs:
+    # 18.2 against 19.2 us and 50.3 against 52.0 for four waves x two m-tiles, gpurun_out/tile_sweep5.log)
+    40: {"qkv": (4, 1, 1, 8, 2, 4, 4), "wo": (2, 2, 2, 2, 4, 4, 4), "w13": (8, 1, 1, 8, 2, 4, 4), "w2": (2, 2, 2, 2, 4, 4, 4),
+         "head": (8, 1, 1, 8, 2, 4, 4)},
     64: {"qkv": (4, 1, 2, 8, 2, 4, 4), "wo": (2, 2, 2, 2, 4, 4, 4), "w13": (4, 1, 2, 8, 2, 4, 4), "w2": (2, 2, 2, 2, 4, 4, 4),
          "head": (4, 1, 2, 8, 2, 4, 4)},
 }

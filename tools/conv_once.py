@@ -10,7 +10,7 @@ variant = int(a[5]) if len(a) > 5 else 0
 abl = int(a[6]) if len(a) > 6 else 0  # 1: no GroupNorm/swish, 2: no residual, 4: no statistics partials
 dev = torch.device("cuda:0")
 lib = L.lib()
-lib.lgen_set_conv_fused_variant(variant)
+lib.lgen_debug_set_conv_fused_variant(variant)
 torch.manual_seed(0)
 class Cv: pass
 cv = Cv(); cv.weight = (torch.randn(Cout, Cin, 3, 3) / (Cin * 9) ** 0.5).to(dev); cv.bias = torch.zeros(Cout, device=dev)

@@ -50,13 +50,13 @@ def sweep(m, rows, out):
     e.state.zero_()
     nl = len(e.layers)
 
+    e.use_tile = False   # this tool sweeps the SKINNY kernels (the big-M tile family: tools/gemm_tile_sweep.py)
+
     def qkv(tl, sc=(1, 0)):
         for w in e.layers:
-            if sc[0] > 1:
-                L.check(lib.lgen_gemm_schedule_hint(sc[0], sc[1]), "hint")
             L.check(lib.lgen_gemm_qkv_rope(L.ptr(w["wqkv"]), L.ptr(e.hp), L.ptr(e.qbuf), L.ptr(e.k_cache[0]), L.ptr(e.v_cache[0]),
                                            L.ptr(e.freqs_cis), L.ptr(e.state), M, mts, d, H, hd, hdp, S8, e.kvs, dt, tl[0], tl[1], tl[2],
-                                           L.ptr(w["an"]), L.ptr(e.ssq), e.ssq_parts, e.eps, L.stream()), "qkv")
+                                           L.ptr(w["an"]), L.ptr(e.ssq), e.ssq_parts, e.eps, sc[0], L.stream()), "qkv")
 
     kinds = {
         "qkv": (qkv, nl, 3 * d * d * 2),
@@ -65,7 +65,7 @@ def sweep(m, rows, out):
         "w2": (lambda tl, sc=None: [e.gemm(w["w2"], e.gp, e.hp, M, mts, d, F, L.EPI_RES, tl, ssq_out=e.ssq) for w in e.layers], nl, F * d * 2),
         "head": (lambda tl, sc=None: [e.gemm(e.out_w, e.hp, e.logits, M, mts, V, d, L.EPI_ROWS, tl, norm_w=e.norm_w, sched=sc) for _ in range(4)], 4, V * d * 2),
     }
-    scheds = [(1, 0), (2, 0), (2, 1), (3, 0), (3, 1), (4, 1), (6, 1), (8, 1)]
+    scheds = [(1, 0), (2, 0), (3, 0), (4, 0), (6, 0), (8, 0)]   # (passes, unused): ABI v7 dropped the double-buffered mode
     cands = {
         # kw = 4 shapes of the fused GEMMs fall through to the ring kernel's RMSNorm prologue (the register-resident form needs
         # 8 waves x 3..6 chunks): the wide-model sweep (profiles/r03_wide_sweep.log) says big tiles x 4 waves are worth a look

@@ -29,29 +29,14 @@ def attn_only(e):
 
 
 def gemms_only(e):
-    lib, st, dt, M, mts = e.lib, L.stream(), e.dt, e.B2, e.MTs
-    d, F, H, hd, hdp, S8 = e.d, e.F, e.H, e.hd, e.hdp, e.S8
-    tq, to, t13, t2, th = (e._tiles("qkv", 3 * d, d), e._tiles("wo", d, d), e._tiles("w13", 2 * F, d), e._tiles("w2", d, F),
-                           e._tiles("head", e.V, d))
-    sq, s13, sh = e._passes("qkv", 3 * d, tq), e._passes("w13", 2 * F, t13), e._passes("head", e.V, th)
-    bq, bo, b13, b2, bh = (e._tile_shape(k) for k in ("qkv", "wo", "w13", "w2", "head"))
-    e.ssq_parts = d // 16
+    nw = lambda w: w if e.fuse_norm else None
+    e.ssq_parts = e.d // 16
     for i, w in enumerate(e.layers):
-        rc = L.ERR_UNSUPPORTED
-        if bq is not None:
-            rc = lib.lgen_gemm_qkv_rope_tile(L.ptr(w["wqkv"]), L.ptr(e.hp), L.ptr(e.qbuf), L.ptr(e.k_cache[i]), L.ptr(e.v_cache[i]),
-                                             L.ptr(e.freqs_cis), L.ptr(e.state), M, mts, d, H, hd, hdp, S8, e.kvs, dt, *bq,
-                                             L.ptr(w["an"]), L.ptr(e.ssq), e.ssq_parts, e.eps, st)
-        if rc == L.ERR_UNSUPPORTED:
-            if sq[0] > 1:
-                lib.lgen_gemm_schedule_hint(sq[0], sq[1])
-            L.check(lib.lgen_gemm_qkv_rope(L.ptr(w["wqkv"]), L.ptr(e.hp), L.ptr(e.qbuf), L.ptr(e.k_cache[i]), L.ptr(e.v_cache[i]),
-                                           L.ptr(e.freqs_cis), L.ptr(e.state), M, mts, d, H, hd, hdp, S8, e.kvs, dt, tq[0], tq[1], tq[2],
-                                           L.ptr(w["an"]), L.ptr(e.ssq), e.ssq_parts, e.eps, 1, st), "qkv")
-        e.gemm(w["wo"], e.ap, e.hp, M, mts, d, d, L.EPI_RES, to, ssq_out=e.ssq, tile=bo)
-        e.gemm(w["w13"], e.hp, e.gp, M, mts, 2 * F, d, L.EPI_SWIGLU, t13, norm_w=w["fn"], sched=s13, tile=b13)
-        e.gemm(w["w2"], e.gp, e.hp, M, mts, d, F, L.EPI_RES, t2, ssq_out=e.ssq, tile=b2)
-    e.gemm(e.out_w, e.hp, e.logits, M, mts, e.V, d, L.EPI_ROWS, th, norm_w=e.norm_w, sched=sh, tile=bh)
+        e.qkv_gemm(i, w, e.hp, nw(w["an"]))
+        e.gemm_kind("wo", w)
+        e.gemm_kind("w13", w, e.hp, nw(w["fn"]))
+        e.gemm_kind("w2", w)
+    e.gemm_kind("head", None, e.hp, nw(e.norm_w))
 
 
 def capture(fn, stream):

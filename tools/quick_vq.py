@@ -11,7 +11,7 @@ def main(B=32, lat=24):
     codes = torch.randint(0, 16384, (B, lat * lat), device=dev)
     from llamagen_amd import _lib as L
     for variant in (3, 0):
-      L.lib().lgen_set_igemm_variant(variant)
+      L.lib().lgen_debug_set_igemm_variant(variant)
       print("igemm variant", variant)
       for r in range(3):
             torch.cuda.synchronize(); t = time.time()

@@ -682,6 +682,7 @@ def main():
                                     "weight_bytes_per_step": int(tot_b), "us_per_step": round(tot_us, 1),
                                     "us_per_step_per_128_rows": round(tot_us * 128 / rows, 1), "schedule": gsched,
                                     "schedule_tested_end_to_end": bool(tested),
+                                    "schedule_source": pipe.lanes[0].gpt._engine.tile_schedule_source(),
                                     "launches_per_step": pipe.lanes[0].gpt._engine.launches_per_step(),
                                     "per_launch": {k: {"us": round(us, 2), "weight_bytes": int(b), "GB/s": round(b / us / 1e3, 1),
                                                        "TFLOPs": round(rows * b / us / 1e6, 1),

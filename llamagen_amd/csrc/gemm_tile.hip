@@ -209,10 +209,11 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_tile_kernel(GemmArgs
 
     // ---- NORM prologue requests: norm weight (shared, every consumer writes the same bytes) + this wave's row statistics ----
     // row statistics staging: the last ring slot (idle until stage STAGES-1 is issued) when a wave's share fits there, else a
-    // dedicated region behind the norm weight (launcher: a.passes = 1 selects the slot, 2 the dedicated region)
+    // dedicated region behind the norm weight (launcher: a.passes = 1 selects the slot, 2 the dedicated region, 3 no staging at
+    // all: wide rows, read from global memory where the row scales are computed)
     unsigned char* s_nw = smem + STAGES * STAGE_B;
     const int nw_bytes = (a.KCH * D::KC * D::ESZ + 1023) / 1024 * 1024;
-    const int ssq_share = MTV * 16 * a.parts * 4;
+    const int ssq_share = (MTV * 16 * a.parts * 4 + 1023) & ~1023;   // whole 1 KiB DMA rounds: the clamped tail lanes stay inside the share
     const unsigned ssq_off = a.passes == 2 ? (unsigned)(STAGES * STAGE_B + nw_bytes + cw * ssq_share)
                                            : (unsigned)((STAGES - 1) * STAGE_B + cw * (STAGE_B / NC));
     unsigned char* s_ssq = smem + ssq_off;
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_tile_kernel(GemmArgs
             off = off < nwb - 16 ? off : nwb - 16;
             __builtin_amdgcn_global_load_lds((gt_gptr_t)((const char*)a.nw + off), (gt_lptr_t)(s_nw + o), 16, 0, 0);
         }
-        const int tot = MTV * 16 * q4;
+        const int tot = a.passes == 3 ? 0 : MTV * 16 * q4;   // passes == 3: the statistics are read straight from global memory below
         for (int o = 0; o < tot; o += 64) {
             int e = o + lane;
             e = e < tot ? e : tot - 1;
@@ -251,8 +252,21 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_tile_kernel(GemmArgs
 #pragma unroll
         for (int i = 0; i < MTV; ++i) {
             const unsigned rowa = ssq0 + (unsigned)((i * 16 + r) * a.parts) * 4;
+            const float* rowg = a.ssq_in + (size_t)((mtw0 + i) * 16 + r) * LGEN_SSQ_STRIDE;
             float s = 0.f;
-            if ((a.parts & 15) == 0 && a.parts <= 128) {
+            if (a.passes == 3) {   // wide rows (GPT-3B: 200 partials x 128 rows = 100 KB would not fit beside the ring): same order, from L2
+                if ((a.parts & 15) == 0 && a.parts <= 128) {
+                    const int n4 = a.parts >> 4;
+#pragma unroll
+                    for (int J = 0; J < 8; ++J)
+                        if (J < n4) {
+                            const float4 v = ((const float4*)rowg)[g * n4 + J];
+                            s += (v.x + v.y) + (v.z + v.w);
+                        }
+                } else {
+                    for (int q = g; q < a.parts; q += 4) s += rowg[q];
+                }
+            } else if ((a.parts & 15) == 0 && a.parts <= 128) {
                 const int n4 = a.parts >> 4;
                 u32x4_t v[8];
                 gt_static_for<0, 8>([&](auto j) {
@@ -415,10 +429,11 @@ static int gt_launch(const GemmArgs& a_in, hipStream_t st) {
     if (NORM) {
         if (a.parts % 4) return LGEN_ERR_UNSUPPORTED;
         lds += ((size_t)a.KCH * D::KC * D::ESZ + 1023) / 1024 * 1024;
-        const size_t share = (size_t)MTV * 16 * a.parts * 4;
-        if (share > (size_t)STAGE_B / NW) {   // the statistics do not fit the idle ring slot: a region of their own
+        const size_t share = ((size_t)MTV * 16 * a.parts * 4 + 1023) & ~(size_t)1023;   // as in the kernel: whole DMA rounds
+        if (share > (size_t)STAGE_B / NW) {   // the statistics do not fit the idle ring slot: a region of their own ...
             a.passes = 2;
-            lds += share * NW;
+            if (lds + share * NW > 160 * 1024) a.passes = 3;   // ... or, when that does not fit either, read from global memory
+            else lds += share * NW;
         }
     }
     if (lds > 160 * 1024) return LGEN_ERR_UNSUPPORTED;

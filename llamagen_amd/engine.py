@@ -95,6 +95,18 @@ def tile_schedule_key(mts: int):
     return max(keys) if keys else None
 
 
+# Every workgroup shape the library instantiates (csrc/gemm_tile.hip GT_SHAPES_NORM / GT_SHAPES_PLAIN): the candidates of the
+# on-device shape search below.  All shapes of the family produce bit-identical results (one wave accumulates an output element
+# over k in order, whatever the tiling: tests/test_gpu_headline.py), so the search only ever changes the speed.
+TILE_SHAPES_NORM = ((4, 1, 1, 3, 4, 4, 4), (4, 1, 1, 4, 4, 4, 4), (4, 1, 1, 6, 2, 4, 4), (4, 1, 1, 6, 4, 3, 4), (4, 1, 1, 8, 2, 4, 4),
+                    (4, 1, 2, 4, 2, 4, 4), (4, 1, 2, 6, 2, 4, 4), (4, 1, 2, 8, 2, 4, 4), (4, 1, 1, 2, 4, 4, 4), (8, 1, 1, 8, 2, 4, 4),
+                    (8, 1, 1, 6, 2, 4, 4), (8, 1, 1, 4, 2, 4, 4))
+TILE_SHAPES_PLAIN = ((2, 2, 1, 1, 4, 4, 4), (2, 2, 1, 2, 4, 4, 4), (2, 2, 2, 1, 4, 4, 4), (2, 2, 2, 2, 4, 4, 4), (2, 2, 2, 2, 2, 4, 4),
+                     (4, 1, 1, 2, 4, 4, 4), (2, 2, 4, 1, 4, 4, 4), (2, 2, 4, 2, 2, 4, 4))
+TABLE_MODEL = (1024, 2816, 16384)   # (dim, ffn hidden, vocab) of GPT-L: the model TILE_SCHEDULES was measured on
+_TUNED = {}   # (device index, dim, F, V, n_head, MTs) -> {kind: shape | None}: one search per process, shared by every lane
+
+
 class PackedWeights:
     """MFMA-fragment-packed copies of a Transformer's parameters (see lgen.h for the layouts)."""
 
@@ -218,6 +230,12 @@ class DecodeEngine:
         # generic NORM prologue (+4 us of exposed VALU work per GEMM).
         kch = self.d // self.kc
         auto = dtype == torch.bfloat16 and kch % 8 == 0 and 3 <= kch // 8 <= 6
+        self.use_tile = os.environ.get("LGEN_GEMM_TILE", "1") != "0"
+        self.tile_autotune = os.environ.get("LGEN_TILE_AUTOTUNE", "1") != "0"
+        # (round 4) the big-M tile family normalises the B fragments between LDS and the MFMA, whatever the row length: chains of
+        # >= 256 rows fuse for every width whose statistics row the kernels take (GPT-3B: d = 3200, 200 partials per row)
+        if dtype == torch.bfloat16 and self.MTs >= 16 and self.use_tile and (self.d // 16) % 4 == 0 and self.d // 16 <= L.SSQ_STRIDE:
+            auto = True
         env = os.environ.get("LGEN_FUSED_NORM")
         self.fuse_norm = auto if env is None else env == "1"
         self.tile_override = {}      # kind ("qkv" | "wo" | "w13" | "w2" | "head") -> (mt, nt, kw)
@@ -233,7 +251,6 @@ class DecodeEngine:
             self.tile_override[kind.strip()] = t
         # fused-norm GEMM schedule (the `passes` argument of lgen_gemm): kind -> (passes, 0); LGEN_PASSES="qkv=2,0;w13=3,0"
         # big-M tile family (round 4): LGEN_GEMM_TILE=0 keeps the skinny kernels; LGEN_TILE_SHAPES="qkv=4,1,1,3,4,4,4;..." picks shapes
-        self.use_tile = os.environ.get("LGEN_GEMM_TILE", "1") != "0"
         self.tile_shape_override = {}
         for item in filter(None, os.environ.get("LGEN_TILE_SHAPES", "").split(";")):
             kind, _, val = item.partition("=")
@@ -356,8 +373,133 @@ class DecodeEngine:
             return None
         if kind == "qkv" and (self.pos_rows is not None or self.hd < 16):
             return None
+        if (self.d, self.F, self.V) != TABLE_MODEL and self.tile_autotune:
+            tuned = self._tuned_shapes()
+            if tuned is not None:
+                return tuned[kind]
         key = tile_schedule_key(self.MTs)
         return None if key is None else TILE_SCHEDULES[key][kind]
+
+    # ---- on-device shape search (models / chain widths without a measured table) ---------------------------------------------
+    def _tile_call(self, kind, w, i, s, x_in, nw):
+        """One launch of the tile family for GEMM `kind` of layer i with workgroup shape s; returns the library's status."""
+        lib, st, dt, M, mts = self.lib, L.stream(), self.dt, self.B2, self.MTs
+        d, F, H, hd, hdp, S8 = self.d, self.F, self.H, self.hd, self.hdp, self.S8
+        if kind == "qkv":
+            return lib.lgen_gemm_qkv_rope_tile(L.ptr(w["wqkv"]), L.ptr(x_in), L.ptr(self.qbuf), L.ptr(self.k_cache[i]),
+                                               L.ptr(self.v_cache[i]), L.ptr(self.freqs_cis), self.state.data_ptr(), M, mts, d, H, hd,
+                                               hdp, S8, self.kvs, dt, *s, L.ptr(nw), L.ptr(self.ssq), self.ssq_parts, self.eps, st)
+        wp, xp, out, N, K, epi, ssq_out = {
+            "wo": (w and w["wo"], self.ap, self.hp, d, d, L.EPI_RES, self.ssq),
+            "w13": (w and w["w13"], x_in, self.gp, 2 * F, d, L.EPI_SWIGLU, None),
+            "w2": (w and w["w2"], self.gp, self.hp, d, F, L.EPI_RES, self.ssq),
+            "head": (self.out_w, x_in, self.logits, self.V, d, L.EPI_ROWS, None)}[kind]
+        return lib.lgen_gemm_tile(L.ptr(wp), L.ptr(xp), L.ptr(out), M, mts, N, K, epi, dt, *s, L.ptr(nw),
+                                  L.ptr(self.ssq) if nw is not None else 0, self.ssq_parts, self.eps, L.ptr(ssq_out), st)
+
+    def _tuned_shapes(self):
+        """{kind: shape | None (skinny kernels)} for this model width and chain width, measured once per process on the device."""
+        key = (self.dev.index, self.d, self.F, self.V, self.H, self.MTs)
+        if key not in _TUNED:
+            if torch.cuda.is_current_stream_capturing():
+                return None          # (never the first use: prefill and the first decode step run eagerly)
+            _TUNED[key] = self._search_tile_shapes()
+        return _TUNED[key]
+
+    def _search_tile_shapes(self):
+        """Times every instantiated workgroup shape of the tile family (and the skinny kernel) for each decode GEMM as a captured
+        pass over ALL layers' weights (nothing stays cache-resident from one launch to the next, as in the decode chain) and keeps
+        the fastest.  Runs on the engine's own workspaces, which it saves and restores; a few hundred launches, once per process
+        per (model width, chain width).  The result only changes speed: every shape gives the same bits."""
+        keep = {n: getattr(self, n).clone() for n in ("hp", "ap", "gp", "qbuf", "ssq", "logits", "state")}
+        pos = int(self.state[0])
+        kv_keep = (self.k_cache[:, :, :, pos].clone(), self.v_cache[:, :, :, pos].clone())
+        parts_keep = self.ssq_parts
+        self.ssq_parts = self.d // 16
+        self.hp.normal_(0, 1)
+        self.ap.zero_()        # wo / w2 add their product to hp in place: a zero operand keeps the repeated passes finite
+        self.gp.zero_()
+        self.ssq.fill_(16.0)
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+
+        def timed(fn):
+            """ms of one captured pass of fn (min of 2 replays after one warm replay), or None when fn reports a failure"""
+            ok = fn()            # eager: loads the code object, reports unsupported shapes before anything is captured
+            if not ok:
+                return None
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                g = torch.cuda.CUDAGraph()
+                g.capture_begin()
+                fn()
+                g.capture_end()
+                g.replay()
+                best = float("inf")
+                for _ in range(2):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    g.replay()
+                    e1.record()
+                    e1.synchronize()
+                    best = min(best, e0.elapsed_time(e1))
+            cur.wait_stream(side)
+            return best
+
+        head_w = [None] * 4
+        nlay = self.layers[:min(len(self.layers), 24)]
+        plan = {"qkv": (nlay, "an", TILE_SHAPES_NORM), "w13": (nlay, "fn", TILE_SHAPES_NORM), "head": (head_w, None, TILE_SHAPES_NORM),
+                "wo": (nlay, None, TILE_SHAPES_PLAIN), "w2": (nlay, None, TILE_SHAPES_PLAIN)}
+        out, report = {}, {}
+        saved_override, saved_auto = self.tile_shape_override, self.tile_autotune
+        self.tile_autotune = False
+        try:
+            for kind, (ws, nkey, shapes) in plan.items():
+                def nw_of(w):
+                    return self.norm_w if kind == "head" else (w[nkey] if nkey else None)
+
+                def skinny():
+                    self.tile_shape_override = {k: None for k in ("qkv", "wo", "w13", "w2", "head")}   # -> the skinny kernels
+                    try:
+                        for i, w in enumerate(ws):
+                            if kind == "qkv":
+                                self.qkv_gemm(i, w, self.hp, nw_of(w))
+                            else:
+                                self.gemm_kind(kind, w, self.hp, nw_of(w))
+                    finally:
+                        self.tile_shape_override = saved_override
+                    return True
+
+                def tile(s):
+                    def run():
+                        for i, w in enumerate(ws):
+                            if self._tile_call(kind, w, i, s, self.hp, nw_of(w)) != 0:
+                                return False
+                        return True
+                    return run
+
+                best_t, best_s = timed(skinny), None
+                report[kind] = {"skinny": best_t}
+                for s in shapes:
+                    if self.MTs % (s[0] * s[2]) or (kind == "w13" and s[3] % 2) or (kind == "qkv" and self.pos_rows is not None):
+                        continue
+                    t = timed(tile(s))
+                    if t is None:
+                        continue
+                    report[kind][s] = t
+                    if t < best_t:
+                        best_t, best_s = t, s
+                out[kind] = best_s
+        finally:
+            self.tile_shape_override, self.tile_autotune = saved_override, saved_auto
+            torch.cuda.current_stream().synchronize()
+            for n, t in keep.items():
+                getattr(self, n).copy_(t)
+            self.k_cache[:, :, :, pos].copy_(kv_keep[0])
+            self.v_cache[:, :, :, pos].copy_(kv_keep[1])
+            self.ssq_parts = parts_keep
+        self.tile_search_report = report
+        return out
 
     def _passes(self, kind: str, N: int, tiles):
         """(passes, double_buffer) of a fused-norm GEMM: n-groups one workgroup walks with its normalised rows kept in registers
@@ -434,6 +576,15 @@ class DecodeEngine:
                       sched=self._passes("head", self.V, th), tile=self._tile_shape("head") if nw is not None else None)
         else:
             raise ValueError(kind)
+
+    def tile_schedule_source(self) -> str:
+        """Where the tile shapes of gemm_schedule() come from: "override" (LGEN_TILE_SHAPES), "table" (TILE_SCHEDULES, measured
+        for GPT-L), "search" (timed on this device at first use), or "none" (chains below 256 rows / other storage types)."""
+        if self.tile_shape_override:
+            return "override"
+        if not self.use_tile or self.MTs < 16 or self.dtype != torch.bfloat16 or not self.fuse_norm:
+            return "none"
+        return "search" if (self.d, self.F, self.V) != TABLE_MODEL and self.tile_autotune else "table"
 
     def gemm_schedule(self) -> dict:
         """The kernel family and shapes the decode graph launches per GEMM kind (bench.py prints it; tests pin it)."""

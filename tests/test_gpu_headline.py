@@ -306,19 +306,26 @@ TILE_PLAIN = [(2, 2, 1, 1, 4, 4, 4), (2, 2, 1, 2, 4, 4, 4), (2, 2, 2, 1, 4, 4, 4
               (4, 1, 1, 2, 4, 4, 4), (2, 2, 1, 1, 4, 4, 0), (2, 2, 4, 1, 4, 4, 4), (2, 2, 4, 2, 2, 4, 4)]
 
 
-@pytest.mark.parametrize("M", [128, 256, 512, 640])
-def test_tile_gemm_family_vs_oracle_and_bit_identical_across_shapes(M):
+TILE_DIMS = {"L": (1024, 16, 64, 2816), "XXL": (1536, 24, 64, 4096), "3B": (3200, 32, 100, 8704)}   # d, heads, head_dim, F
+
+
+@pytest.mark.parametrize("M,width", [(128, "L"), (256, "L"), (512, "L"), (640, "L"), (256, "XXL"), (256, "3B")])
+def test_tile_gemm_family_vs_oracle_and_bit_identical_across_shapes(M, width):
     """Big-M tile family (csrc/gemm_tile.hip, round 4) at GPT-L sizes: every instantiated workgroup shape of lgen_gemm_tile /
     lgen_gemm_qkv_rope_tile -- loader waves or not, any tile, any ring depth -- accumulates an output element in ONE wave over k
     in order, so ALL shapes must agree BIT for bit; the first is held to the oracle: fused RMSNorm (scales bit-identical to the
     skinny kernels': same statistics, same summation order) + wqkv + RoPE + KV append, + w1||w3 + SwiGLU, + lm_head rows, and the
     plain form wo / w2 + residual + the next norm's statistics.  (F = 2816: K = 88 chunks for w2; N = 5632 does not divide every
-    tile width: the ragged last n-group is exercised.)"""
+    tile width: the ragged last n-group is exercised.)  Widths XXL and 3B: the same at GPT-XXL / GPT-3B sizes -- 3B has head_dim 100
+    (q / K / V rows padded to 128, q|k|v sections that are no multiple of a 16-column tile) and 200 partial sums of squares per
+    row: too many for the LDS staging of the larger shapes, which read them from global memory instead (same order, same bits)."""
     from llamagen_amd.engine import pack_act, pack_weight, precompute_freqs_cis_2d, unpack_act
     from tests.test_gpu_gpt import _close, _rand
     L, dev = _L(), _dev()
     lib = L.lib()
-    dt, d, H, hd, F, V, grid, pos = torch.bfloat16, 1024, 16, 64, 2816, 2048, 24, 77
+    dt, V, grid, pos = torch.bfloat16, 2048, 24, 77
+    d, H, hd, F = TILE_DIMS[width]
+    hdp = 64 if hd <= 64 else 128
     S8 = O.find_multiple(1 + grid * grid, 8)
     mts = M // 16
     x = _rand((M, d), dt, 61, 1.3)
@@ -336,13 +343,13 @@ def test_tile_gemm_family_vs_oracle_and_bit_identical_across_shapes(M):
     state = torch.tensor([pos, 0], dtype=torch.int32, device=dev)
 
     def run_norm(s):
-        kc = torch.zeros(M, H, S8, 64, dtype=dt, device=dev)
-        vc = torch.zeros(M, H, S8, 64, dtype=dt, device=dev)
-        q = torch.zeros(mts * 16, H, 64, dtype=dt, device=dev)
+        kc = torch.zeros(M, H, S8, hdp, dtype=dt, device=dev)
+        vc = torch.zeros(M, H, S8, hdp, dtype=dt, device=dev)
+        q = torch.zeros(mts * 16, H, hdp, dtype=dt, device=dev)
         gp = torch.zeros(F // 32, mts, 64, 8, dtype=dt, device=dev)
         rows = torch.zeros(mts * 16, V, dtype=dt, device=dev)
         rcs = [lib.lgen_gemm_qkv_rope_tile(L.ptr(wqp), L.ptr(xp), L.ptr(q), L.ptr(kc), L.ptr(vc), L.ptr(fr_d), L.ptr(state), M, mts, d,
-                                           H, hd, 64, S8, 0, L.BF16, *s, L.ptr(nw_d), L.ptr(ssq), d // 16, 1e-5, L.stream())]
+                                           H, hd, hdp, S8, 0, L.BF16, *s, L.ptr(nw_d), L.ptr(ssq), d // 16, 1e-5, L.stream())]
         if s[3] % 2 == 0:
             rcs.append(lib.lgen_gemm_tile(L.ptr(w13), L.ptr(xp), L.ptr(gp), M, mts, 2 * F, d, L.EPI_SWIGLU, L.BF16, *s, L.ptr(nw_d),
                                           L.ptr(ssq), d // 16, 1e-5, 0, L.stream()))
@@ -359,7 +366,8 @@ def test_tile_gemm_family_vs_oracle_and_bit_identical_across_shapes(M):
         kc[:, :, pos] = 0
         vc[:, :, pos] = 0
         assert not kc.any() and not vc.any(), s     # nothing but slot `pos` was written
-        return dict(q=q, k=kw, v=vw, swiglu=gp, logits=rows)
+        assert not q[..., hd:].any() and not kw[..., hd:].any() and not vw[..., hd:].any(), s   # pad lanes stay zero
+        return dict(q=q[..., :hd].contiguous(), k=kw[..., :hd].contiguous(), v=vw[..., :hd].contiguous(), swiglu=gp, logits=rows)
 
     def run_plain(s):
         out = {}
@@ -498,18 +506,36 @@ def test_decode_code_batch32_384px_vs_oracle():
     assert worst < 1e-3, worst  # north_star: decoded pixels within 1e-3 abs
 
 
-def test_config4_gpt3b_shapes_bf16_vs_oracle():
+def _searched_tile_schedule(e):
+    """A chain of >= 256 rows of a model without a measured table: RMSNorm fused, tile shapes from the on-device search (every
+    GEMM kind got either an instantiated shape or the skinny kernels), the search left the workspaces as it found them."""
+    from llamagen_amd.engine import TILE_SHAPES_NORM, TILE_SHAPES_PLAIN
+    assert e.fuse_norm and e.tile_schedule_source() == "search"
+    sched = e.gemm_schedule()
+    fam = {k: v["family"] for k, v in sched.items()}
+    for k, v in sched.items():
+        if v["family"] == "tile":
+            assert tuple(v["shape(wm,wn,mtv,ntv,kb,stages,lw)"]) in (TILE_SHAPES_PLAIN if k in ("wo", "w2") else TILE_SHAPES_NORM), sched
+    assert "tile" in fam.values(), (sched, e.tile_search_report if hasattr(e, "tile_search_report") else None)
+    return sched
+
+
+@pytest.mark.parametrize("B", [64, 128])
+def test_config4_gpt3b_shapes_bf16_vs_oracle(B):
     """BASELINE config 4 kernel shapes: GPT-3B widths (d 3200, 32 heads, head_dim 100 -> padded 128, F 8704),
-    B = 64 -> 128 rows (MTs 8), 384 px (S8 584); depth cut to 4 layers so that the oracle finishes in seconds."""
+    B = 64 -> 128 rows (MTs 8), 384 px (S8 584); depth cut to 4 layers so that the oracle finishes in seconds.
+    B = 128: the 256-row chain `bench.py --config 4` runs (two batches of 64): RMSNorm fused (200 partial sums per row), the
+    big-M tile family with shapes from the on-device search."""
     kw = dict(n_layer=4, n_head=32, dim=3200, vocab_size=16384, block_size=576, num_classes=1000, cls_token_num=1,
               model_type="c2i")
     case = dict(kwargs=kw, wseed=22, lin_std=0.02)
-    B = 64
     cond = torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(4))
     recs, m = _teacher_forced(case, B, 4.0, early=3, late=[420], cond=cond)
     e = m._engine
-    assert e.hd == 100 and e.hdp == 128 and e.MTs == 8 and e.F == 8704
-    _check("config4_gpt3b_shapes", recs)
+    assert e.hd == 100 and e.hdp == 128 and e.MTs == B // 8 and e.F == 8704
+    if B == 128:
+        _log("config4_gpt3b_shapes_256rows", dict(schedule=str(_searched_tile_schedule(e))))
+    _check(f"config4_gpt3b_shapes_b{B}", recs)
 
 
 def test_config5_gptxl_t2i_shapes_bf16_vs_oracle():
@@ -533,17 +559,19 @@ def test_config5_gptxl_t2i_shapes_bf16_vs_oracle():
     _check("config5_gptxl_t2i_shapes", recs)
 
 
-def test_config3_gptxxl_shapes_bf16_vs_oracle():
+@pytest.mark.parametrize("B", [32, 128])
+def test_config3_gptxxl_shapes_bf16_vs_oracle(B):
     """BASELINE config 3 per-GPU kernel shapes: GPT-XXL widths (d 1536, 24 heads, F 4096; fused-norm CPW 6), B = 32 -> 64
     rows, 384 px; depth cut to 4 layers."""
     kw = dict(n_layer=4, n_head=24, dim=1536, vocab_size=16384, block_size=576, num_classes=1000, cls_token_num=1,
               model_type="c2i")
     case = dict(kwargs=kw, wseed=24, lin_std=0.02)
-    B = 32
     cond = torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(6))
     recs, m = _teacher_forced(case, B, 4.0, early=3, late=[575], cond=cond)
     assert m._engine.fuse_norm
-    _check("config3_gptxxl_shapes", recs)
+    if B == 128:   # the 256-row chain `bench.py --config 3` runs (four batches of 32): tile family, searched shapes
+        _log("config3_gptxxl_shapes_256rows", dict(schedule=str(_searched_tile_schedule(m._engine))))
+    _check(f"config3_gptxxl_shapes_b{B}", recs)
 
 
 @pytest.mark.parametrize("name", ["gptxxl_c3", "gpt3b_c4", "gptxl_t2i_c5"])

@@ -95,9 +95,16 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_tile_kernel(GemmArgs
     const int wm = cw / WN, wn = cw - wm * WN;
     const int ntiles = a.N >> 4;
     const int gx = (ntiles + NTW - 1) / NTW, gy = a.MTs / MTW;
-    const int bid = blockIdx.x, slot0 = bid >> 3;
-    const int by = slot0 % gy, bx = (slot0 / gy) * 8 + (bid & 7);
-    if (bx >= gx) return;  // padding of the decoded grid (whole workgroup, before any barrier)
+    // Block id -> tile.  Workgroups are dealt to the 8 XCDs round-robin (XCD = bid & 7), each XCD has its own L2: XCD x owns the
+    // column groups bx = xc (mod XC) of the row groups by = xrow (mod XR), x = xrow * XC + xc, XR * XC = 8, row groups fastest (the
+    // workgroups that share a weight tile run together).  XR = 1 (every XCD reads ALL activation rows, each weight byte enters
+    // one L2): right while the weights outweigh the row panel; the launcher picks XR = 2 / 4 where 8 copies of the row panel cost
+    // more than 2 / 4 copies of the weights (wo / w2 of a 640-row chain: 34.6 -> 25.9 MB of L2 fills per launch).
+    const int bid = blockIdx.x, xrl = (a.db >> 8) & 3, XR = 1 << xrl, XC = 8 >> xrl;
+    const int xcd = bid & 7, slot0 = bid >> 3;
+    const int gyl = (gy + XR - 1) >> xrl;
+    const int by = (slot0 % gyl) * XR + (xcd >> (3 - xrl)), bx = (slot0 / gyl) * XC + (xcd & (XC - 1));
+    if (bx >= gx || by >= gy) return;  // padding of the decoded grid (whole workgroup, before any barrier)
     const int nt0 = bx * NTW, mt0 = by * MTW;
     const int NI = a.KCH / KB;          // ring stages over K (launcher: KCH % KB == 0, NI >= STAGES - 1)
     const int mtw0 = mt0 + wm * MTV, ntw0 = nt0 + wn * NTV;   // this wave's first m-tile / n-tile
@@ -418,6 +425,11 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_tile_kernel(GemmArgs
     }
 }
 
+static int gt_xr_override() {   // development switch LGEN_TILE_XR=0|1|2: log2 of the row split over XCDs (default: chosen per launch)
+    static const int v = [] { const char* e = getenv("LGEN_TILE_XR"); return e ? atoi(e) : -1; }();
+    return v < 0 || v > 2 ? -1 : v;
+}
+
 // ---- launch table ---------------------------------------------------------------------------------------------------------
 template <typename D, int WM, int WN, int MTV, int NTV, int KB, int STAGES, int EPI, bool NORM, int LW>
 static int gt_launch(const GemmArgs& a_in, hipStream_t st) {
@@ -444,7 +456,23 @@ static int gt_launch(const GemmArgs& a_in, hipStream_t st) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(kern, dim3(8 * ((gx + 7) / 8) * gy), dim3(64 * (NW + LW)), lds, st, a);
+    // rows split over XR groups of XCDs (see the block-id decode in the kernel): the balanced split with the fewest L2 fills
+    int xrl = gt_xr_override();
+    if (xrl < 0) {
+        const double xb = (double)a.MTs * 16 * a.KCH, wb = (double)a.N * a.KCH;   // row panel / weights, in k-chunk rows
+        double best = 8 * xb + wb;
+        xrl = 0;
+        for (int l = 1; l <= 2; ++l)
+            if (gy % (1 << l) == 0 && (8 >> l) * xb + (1 << l) * wb < 0.95 * best) {
+                best = (8 >> l) * xb + (1 << l) * wb;
+                xrl = l;
+            }
+    } else if (gy % (1 << xrl)) {
+        xrl = 0;
+    }
+    a.db = (a.db & 0xff) | (xrl << 8);
+    const int XR = 1 << xrl, XC = 8 >> xrl;
+    hipLaunchKernelGGL(kern, dim3(8 * ((gx + XC - 1) / XC) * ((gy + XR - 1) / XR)), dim3(64 * (NW + LW)), lds, st, a);
     LGEN_CHECK_LAUNCH();
     return 0;
 }

@@ -311,7 +311,7 @@ def test_qkv_rope_append_and_attention(dt, B2, H, hd, grid, pos, interleave):
     kcd = _kc(dt)
     variants = [(False, 0), (True, 0), (False, 1), (True, 1), (False, 2), (True, 3), (True, 4), (False, 5)]
     variants += [(um, v) for v, hpw in ((6, 2), (7, 4)) if H % hpw == 0 for um in (False, True)]  # round 3: 2 / 4 heads per workgroup
-    variants += [(um, v) for v in (8, 9, 10, 11, 12, 13) for um in (False, True)]  # round 4: persistent form (one / two 8-wave, one 4-wave workgroup per CU)
+    variants += [(um, v) for v in (8, 9, 10, 11, 12, 13, 14) for um in (False, True)]  # round 4: persistent form (one / two 8-wave, one 4-, 2-, 1-, 3-wave workgroup per CU)
     variants += [(False, -1), (True, -1)]   # the library's own choice for this shape
     for use_mask, variant in variants:
         mask = torch.tril(torch.ones(S8, S8, dtype=torch.bool)).unsqueeze(0).repeat(B2, 1, 1)

@@ -7,6 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 d, H, hd, F, V = 1024, 16, 64, 2816, 16384
 B2 = 2 * int(os.environ.get("LGEN_PMC_B", "320"))  # rows of the decode chain (tools/pmc_target.py)
 TAG = os.environ.get("LGEN_PMC_TAG", "r04")
+XROW = B2 * d * 2   # bytes of one [rows, d] bf16 panel: the activation operand of a GEMM (and the residual a RES epilogue reads)
 GEMM = {  # kernel-name fragment -> (bench key, algorithmic weight bytes)
     "EPI_QKV": ("wqkv", 3 * d * d * 2), "5, 4>(GemmArgs)": ("wqkv", 3 * d * d * 2),
 }
@@ -20,7 +21,7 @@ def rows(pattern):
 
 
 def classify(name, grid):
-    """decode-chain kernel -> (key, algorithmic bytes read) for GPT-L."""
+    """decode-chain kernel -> (key, algorithmic bytes read: weights + activation rows [+ residual rows]) for GPT-L."""
     if "attn_decode" in name:   # attn_decode_kernel / attn_decode_persist_kernel
         return "attn", None
     if "gemm_normpre_kernel" in name or "gemm_kernel" in name or "gemm_steady_kernel" in name or "gemm_tile_kernel" in name:
@@ -28,11 +29,11 @@ def classify(name, grid):
         args = name[name.index("<") + 1:name.index(">")].split(",")
         epi = int(args[7 if "gemm_tile_kernel" in name else 3])
         if epi == 5:
-            return "wqkv", 3 * d * d * 2
+            return "wqkv", 3 * d * d * 2 + XROW
         if epi == 4:
-            return "w13", 2 * F * d * 2
+            return "w13", 2 * F * d * 2 + XROW
         if epi == 0:
-            return "lm_head", V * d * 2
+            return "lm_head", V * d * 2 + XROW
         if epi == 3:
             return "res", None  # wo (d x d) and w2 (d x F) share the instantiation: split by grid size below
     return None, None
@@ -63,7 +64,7 @@ def main(fetch_dir, write_dir):
             a[1] += val
         res_seq.sort()
         for i, (_, val) in enumerate(res_seq):  # per layer: ... attention, wo (RES), w1||w3, w2 (RES) ...
-            key, alg = ("wo", d * d * 2) if i % 2 == 0 else ("w2", F * d * 2)
+            key, alg = ("wo", d * d * 2 + 2 * XROW) if i % 2 == 0 else ("w2", F * d * 2 + B2 * F * 2 + XROW)   # + operand rows + residual rows
             a = acc.setdefault(key, [0, 0.0, alg])
             a[0] += 1
             a[1] += val

@@ -68,15 +68,19 @@ def plan_schedule(args, B, N, T):
         bpc = args.batches_per_chain
     elif args.config == 2:
         bpc = max(1, min(12, (args.steps + 1) // 2))   # <= 768 rows: the tile shapes tests/test_gpu_headline.py holds to the oracle
+    elif args.config == 3:
+        # GPT-XXL: two chains of up to six batches (384 rows) -- 42.0 img/s against 39.2 for three chains of four (round 4, same box
+        # class, profiles/r04_bench_config3.json); 2 x 6 x (10.6 GB of KV + 1.2 GB of noise) = 142 GB resident
+        bpc = max(1, min(6, (args.steps + 1) // 2))
     else:
-        bpc = {3: 4, 4: 2, 5: 4}[args.config]
+        bpc = {4: 2, 5: 4}[args.config]   # GPT-3B: 4 batches x 1 chain measured 25.2 img/s against 28.2 for 2 x 2
     chains = (args.steps + bpc - 1) // bpc
     n_layer, n_head, dim = GPT_DIMS[CONFIGS[args.config]["gpt"]]
     hdp = 64 if dim // n_head <= 64 else 128
     per_chain = (n_layer * 2 * B * bpc * n_head * (T + N + 8) * hdp * 2 * 2      # K and V slabs, CFG rows
                  + N * B * bpc * 16384 * 4)                                       # Exp(1) noise
     if args.lanes <= 0:
-        if args.config == 2:
+        if args.config in (2, 3):
             args.lanes = min(2, chains)
         else:
             # k chains in flight take ~T_k (round 3, 256-row chains with the decoder in 32-image pieces: 1, 1.71, 2.49 -- tools/exp_r3c.py);

@@ -104,7 +104,7 @@ TILE_SHAPES_NORM = ((4, 1, 1, 3, 4, 4, 4), (4, 1, 1, 4, 4, 4, 4), (4, 1, 1, 6, 2
 TILE_SHAPES_PLAIN = ((2, 2, 1, 1, 4, 4, 4), (2, 2, 1, 2, 4, 4, 4), (2, 2, 2, 1, 4, 4, 4), (2, 2, 2, 2, 4, 4, 4), (2, 2, 2, 2, 2, 4, 4),
                      (4, 1, 1, 2, 4, 4, 4), (2, 2, 4, 1, 4, 4, 4), (2, 2, 4, 2, 2, 4, 4))
 TABLE_MODEL = (1024, 2816, 16384)   # (dim, ffn hidden, vocab) of GPT-L: the model TILE_SCHEDULES was measured on
-_TUNED = {}   # (device index, dim, F, V, n_head, MTs) -> {kind: shape | None}: one search per process, shared by every lane
+_TUNED = {}   # (device index, dim, F, V, n_head, MTs, per-row positions?) -> {kind: shape | None}: one search per process, shared by every lane
 
 
 class PackedWeights:
@@ -399,7 +399,7 @@ class DecodeEngine:
 
     def _tuned_shapes(self):
         """{kind: shape | None (skinny kernels)} for this model width and chain width, measured once per process on the device."""
-        key = (self.dev.index, self.d, self.F, self.V, self.H, self.MTs)
+        key = (self.dev.index, self.d, self.F, self.V, self.H, self.MTs, self.pos_rows is not None)
         if key not in _TUNED:
             if torch.cuda.is_current_stream_capturing():
                 return None          # (never the first use: prefill and the first decode step run eagerly)
@@ -455,6 +455,12 @@ class DecodeEngine:
         self.tile_autotune = False
         try:
             for kind, (ws, nkey, shapes) in plan.items():
+                if kind == "qkv" and self.pos_rows is not None:
+                    # continuous batching: wqkv stays on the per-row-position skinny kernel (_tile_shape); timing it here would
+                    # append K/V rows at every request's own position, which the save / restore around the search does not cover
+                    out[kind] = None
+                    continue
+
                 def nw_of(w):
                     return self.norm_w if kind == "head" else (w[nkey] if nkey else None)
 
@@ -481,7 +487,7 @@ class DecodeEngine:
                 best_t, best_s = timed(skinny), None
                 report[kind] = {"skinny": best_t}
                 for s in shapes:
-                    if self.MTs % (s[0] * s[2]) or (kind == "w13" and s[3] % 2) or (kind == "qkv" and self.pos_rows is not None):
+                    if self.MTs % (s[0] * s[2]) or (kind == "w13" and s[3] % 2):
                         continue
                     t = timed(tile(s))
                     if t is None:

@@ -78,6 +78,11 @@ def test_hbm_budget_is_checked_before_allocation():
     assert r.returncode == 0, r.stderr[-2000:]
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert j["batches_per_chain"] == 10 and j["chains_in_flight_per_gpu"] == 2 and j["kv_plus_noise_GB_per_chain"] < 60
+    # config 3 per-GPU shape (GPT-XXL): two chains of six batches fit (2 x 73.5 GB), which is what the default plan picks
+    r = _run_bench(["--config", "3", "--steps", "12", "--budget-check-only"], timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert (j["batches_per_chain"], j["chains_in_flight_per_gpu"]) == (6, 2) and 2 * j["kv_plus_noise_GB_per_chain"] < j["budget_GB"]
 
 
 def test_bench_torchrun_form_and_world_mismatch():

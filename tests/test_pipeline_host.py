@@ -91,3 +91,30 @@ def test_callable_conds_are_drawn_in_batch_order_and_sizes_must_match():
         pass
     else:
         raise AssertionError("batches of different sizes must not share a chain")
+
+
+def test_prepare_gives_every_lane_one_whole_chain_c2i_and_t2i(monkeypatch):
+    """prepare() = one throw-away chain PER LANE (slabs allocated, graph captured before any timed run), for class- and for
+    text-conditional models alike: with batches_per_chain > 1 that is bpc conditioning batches per lane (round-3 advisor finding:
+    the t2i branch used to submit one batch per lane, which run() packed into a single chain on lane 0)."""
+    import types
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    for model_type in ("c2i", "t2i"):
+        lanes = [_Lane(steps=2) for _ in range(3)]
+        lanes[0].gpt = types.SimpleNamespace(model_type=model_type, num_classes=1000, cls_token_num=5,
+                                             config=types.SimpleNamespace(caption_dim=8),
+                                             tok_embeddings=types.SimpleNamespace(weight=torch.zeros(1, dtype=torch.float32)))
+        pipe = _Pipe(lanes, bpc=4)
+        seen = []
+
+        def start(self, job_id, cond, max_new_tokens, decode_shape, gen_kw, _seen=seen):
+            more = gen_kw.get("_more_conds") or []
+            assert not any(isinstance(c, PadBatch) for c in more)          # whole chains: nothing to pad
+            _seen.append((id(self), 1 + len(more), cond.shape[0]))
+            self.job, self.left = (job_id, torch.zeros(cond.shape[0] * (1 + len(more)), dtype=torch.long), max_new_tokens, decode_shape), 1
+        monkeypatch.setattr(_Lane, "start", start)
+        pipe.prepare(batch=2, max_new_tokens=3)
+        monkeypatch.undo()
+        monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+        assert sorted(s[0] for s in seen) == sorted(id(l) for l in lanes), (model_type, seen)   # every lane ran exactly one chain
+        assert all(nb == 4 and rows == 2 for _, nb, rows in seen), (model_type, seen)

@@ -620,10 +620,13 @@ static int gt_launch(const GemmArgs& a_in, hipStream_t st) {
 #define GT_SHAPES_NORM(X)                                                                                        \
     X(4, 1, 1, 3, 4, 4, 4) X(4, 1, 1, 4, 4, 4, 4) X(4, 1, 1, 6, 2, 4, 4) X(4, 1, 1, 6, 4, 3, 4) X(4, 1, 1, 8, 2, 4, 4) \
     X(4, 1, 2, 4, 2, 4, 4) X(4, 1, 2, 6, 2, 4, 4) X(4, 1, 2, 8, 2, 4, 4) X(4, 1, 1, 2, 4, 4, 4) X(4, 1, 1, 3, 4, 4, 0) \
-    X(8, 1, 1, 8, 2, 4, 4) X(8, 1, 1, 6, 2, 4, 4) X(8, 1, 1, 4, 2, 4, 4)
+    X(8, 1, 1, 8, 2, 4, 4) X(8, 1, 1, 6, 2, 4, 4) X(8, 1, 1, 4, 2, 4, 4)                                          \
+    /* deeper rings (round-5 candidates: more operand bytes in flight per CU for the contended regime) */ \
+    X(4, 1, 1, 8, 2, 6, 4) X(4, 1, 1, 8, 2, 5, 4)
 #define GT_SHAPES_PLAIN(X)                                                                                       \
     X(2, 2, 1, 1, 4, 4, 4) X(2, 2, 1, 2, 4, 4, 4) X(2, 2, 2, 1, 4, 4, 4) X(2, 2, 2, 2, 4, 4, 4) X(2, 2, 2, 2, 2, 4, 4) \
-    X(4, 1, 1, 2, 4, 4, 4) X(2, 2, 1, 1, 4, 4, 0) X(2, 2, 4, 1, 4, 4, 4) X(2, 2, 4, 2, 2, 4, 4)
+    X(4, 1, 1, 2, 4, 4, 4) X(2, 2, 1, 1, 4, 4, 0) X(2, 2, 4, 1, 4, 4, 4) X(2, 2, 4, 2, 2, 4, 4)                   \
+    X(2, 2, 2, 2, 2, 9, 4) X(2, 2, 2, 2, 2, 6, 4)
 
 // LN shapes (WM, WN, MTV, NTV, KB, STAGES), lw code 12
 #define GT_SHAPES_LN(X) X(2, 2, 4, 4, 2, 4) X(2, 2, 2, 4, 2, 4) X(2, 2, 4, 2, 2, 4) X(2, 2, 2, 2, 4, 4) X(4, 2, 2, 4, 2, 4) X(2, 4, 4, 2, 2, 4)

@@ -117,14 +117,14 @@ struct QkvCol {
 // reads, RMSNorm, MFMA, epilogue) + LW loader waves (DMA issue and the counted waits only); a workgroup's waves are dealt to
 // the SIMDs round-robin, so every SIMD holds one consumer and one loader and the DMA issue overlaps the MFMA / VALU work.
 //
-// LN (round 5 candidate, shapes with lw code 12): the four loader waves ALSO apply the RMSNorm.  They pull the activation
+// LN (round 5 candidate, shapes with lw code 12 = four / 16 = eight loader waves): the loader waves ALSO apply the RMSNorm.  They pull the activation
 // fragments of their row tiles through registers (asm `global_load_dwordx4`, a STAGES-deep register ring), normalise each
 // fragment ONCE per workgroup and `ds_write_b128` it into the ring slot as the finished MFMA operand; the weights keep the DMA
 // path.  The consumers then are the plain ones (no norm VALU, no norm-weight read) and can take 2-D wave tiles (64 x 64: 8
 // LDS reads per 16 MFMAs instead of 9 per 8), which the consumer-side norm could not afford (every N-wave would repeat it).
 template <typename D, int WM, int WN, int MTV, int NTV, int KB, int STAGES, int EPI, bool NORM, int LW, bool LN = false>
 __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_tile_kernel(GemmArgs a) {
-    static_assert(!LN || (LW == 4 && !NORM), "LN: four loader waves normalise, the consumers are the plain ones");
+    static_assert(!LN || ((LW == 4 || LW == 8) && !NORM), "LN: four or eight loader waves normalise, the consumers are the plain ones");
     constexpr int NC = WM * WN, NL = LW ? LW : NC, MTW = WM * MTV, NTW = WN * NTV;
     constexpr int CPK = MTW + NTW;      // 1 KiB chunks per k-chunk of the workgroup tile
     constexpr int CPS = KB * CPK;       // chunks per ring stage
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_tile_kernel(GemmArgs
             static_assert(STAGES == 4, "LN: the counted waits below are written out for a four-slot ring");
             constexpr int RT = MTW / NL;            // row tiles of this loader wave
             constexpr int FB = KB * RT;             // activation fragments per stage (register path)
-            constexpr int XG = FB + KB;             // vm operations of one stage's register group (+ one norm-weight slice per k-chunk)
+            constexpr int XG = FB;                  // vm operations of one stage's register group
             constexpr int PA = KB * NTW / NL;       // weight pieces per stage (DMA path)
             static_assert(3 * (XG + PA) <= 60, "vmcnt is a 6-bit counter");
             const int r = lane & 15, g = lane >> 4;
@@ -187,11 +187,20 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_tile_kernel(GemmArgs
                 sum += __shfl_xor(sum, 32, 64);
                 ri[t] = 1.0f / sqrtf(sum * a.inv_k + a.eps);
             }
+            // norm weight -> LDS behind the ring (every loader wave writes the same bytes and waits for its own copy: no barrier)
+            {
+                const int nwb = a.KCH * D::KC * D::ESZ;
+                for (int o = 0; o < nwb; o += 1024) {
+                    int off = o + lane * 16;
+                    off = off < nwb - 16 ? off : nwb - 16;
+                    __builtin_amdgcn_global_load_lds((gt_gptr_t)((const char*)a.nw + off), (gt_lptr_t)(smem + STAGES * STAGE_B + o), 16, 0, 0);
+                }
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing of the prologue stays in the counted window below
-            // register ring: X[set][kk * RT + t] raw fragments, Wv[set][kk] norm-weight slices of stage s in set s % STAGES
-            u32x4_t X[STAGES][FB], Wv[STAGES][KB];
+            const unsigned ldsN = lds0 + STAGES * STAGE_B + g * 16;
+            // register ring: X[set][kk * RT + t] raw fragments of stage s in set s % STAGES
+            u32x4_t X[STAGES][FB];
             const uint4* xsrc = a.xp + ((size_t)0 * a.MTs + mt0 + lw * RT) * 64 + lane;   // + (kchunk * MTs + t) * 64
-            const char* nsrc = (const char*)a.nw + g * 16;                                   // + kchunk * 64
             auto xload = [&](auto set_, int s) {   // stage s -> register set
                 constexpr int SET = decltype(set_)::value;
                 gt_static_for<0, KB>([&](auto kk_) {
@@ -201,7 +210,6 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_tile_kernel(GemmArgs
                         constexpr int T = decltype(t_)::value;
                         X[SET][KK * RT + T] = gt_gload(px + T * 64);
                     });
-                    Wv[SET][KK] = gt_gload(nsrc + (size_t)(s * KB + KK) * 64);
                 });
             };
             const uint4* asrc[PA];
@@ -220,13 +228,16 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_tile_kernel(GemmArgs
                     asrc[p] += KB * 64;
                 }
             };
-            auto put = [&](auto set_, int slot) {   // normalise register set -> ring slot, visible to the workgroup after the next barrier
+            auto put = [&](auto set_, int slot, int s) {   // normalise register set (stage s) -> ring slot, visible after the next barrier
                 constexpr int SET = decltype(set_)::value;
                 const unsigned base = lds0 + slot * STAGE_B + (lw * RT) * 1024 + lane * 16;
+                u32x4_t Wv[KB];
+                gt_static_for<0, KB>([&](auto kk_) { Wv[decltype(kk_)::value] = gt_lds_rd<decltype(kk_)::value * 64>(ldsN + (unsigned)(s * KB) * 64); });
+                gt_wait_lgkm<0>();
                 gt_static_for<0, KB>([&](auto kk_) {
                     constexpr int KK = decltype(kk_)::value;
-                    gt_touch(Wv[SET][KK]);
-                    const uint4 wn4 = gt_u4(Wv[SET][KK]);
+                    gt_touch(Wv[KK]);
+                    const uint4 wn4 = gt_u4(Wv[KK]);
                     gt_static_for<0, RT>([&](auto t_) {
                         constexpr int T = decltype(t_)::value;
                         gt_touch(X[SET][KK * RT + T]);
@@ -245,7 +256,7 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_tile_kernel(GemmArgs
                 if constexpr (S >= 1) issueA(S - 1);
             });
             gt_wait_vm<(STAGES - 1) * (XG + PA)>();            // x(0) landed
-            put(std::integral_constant<int, 0>{}, 0);
+            put(std::integral_constant<int, 0>{}, 0, 0);
             for (int it0 = 0; it0 < NI; it0 += STAGES) {
                 gt_static_for<0, STAGES>([&](auto r_) {
                     constexpr int R = decltype(r_)::value;
@@ -261,7 +272,7 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_tile_kernel(GemmArgs
                         asm volatile("" ::: "memory");
                         if (it + STAGES < NI) xload(r_, it + STAGES);                                       // into the set x(it) left
                         if (it + STAGES - 1 < NI) issueA((R + STAGES - 1) % STAGES);                        // the slot stage it-1 left
-                        if (it + 1 < NI) put(std::integral_constant<int, (R + 1) % STAGES>{}, (R + 1) % STAGES);
+                        if (it + 1 < NI) put(std::integral_constant<int, (R + 1) % STAGES>{}, (R + 1) % STAGES, it + 1);
                     }
                 });
             }
@@ -574,8 +585,9 @@ static int gt_launch(const GemmArgs& a_in, hipStream_t st) {
     GemmArgs a = a_in;
     constexpr int NW = WM * WN, MTW = WM * MTV, NTW = WN * NTV, CPS = KB * (MTW + NTW), STAGE_B = CPS * 1024;
     if (a.MTs % MTW || a.KCH % KB || a.KCH / KB < STAGES - 1) return LGEN_ERR_UNSUPPORTED;
-    if (LN && (a.KCH / KB < STAGES || a.parts % 4)) return LGEN_ERR_UNSUPPORTED;
+    if (LN && a.KCH / KB < STAGES) return LGEN_ERR_UNSUPPORTED;
     size_t lds = (size_t)STAGES * STAGE_B;
+    if (LN) lds += ((size_t)a.KCH * D::KC * D::ESZ + 1023) / 1024 * 1024;   // the norm weight behind the ring (read by the loader waves)
     a.passes = 1;
     if (NORM) {
         if (a.parts % 4) return LGEN_ERR_UNSUPPORTED;
@@ -628,8 +640,12 @@ static int gt_launch(const GemmArgs& a_in, hipStream_t st) {
     X(4, 1, 1, 2, 4, 4, 4) X(2, 2, 1, 1, 4, 4, 0) X(2, 2, 4, 1, 4, 4, 4) X(2, 2, 4, 2, 2, 4, 4)                   \
     X(2, 2, 2, 2, 2, 9, 4) X(2, 2, 2, 2, 2, 6, 4)
 
-// LN shapes (WM, WN, MTV, NTV, KB, STAGES), lw code 12
-#define GT_SHAPES_LN(X) X(2, 2, 4, 4, 2, 4) X(2, 2, 2, 4, 2, 4) X(2, 2, 4, 2, 2, 4) X(2, 2, 2, 2, 4, 4) X(4, 2, 2, 4, 2, 4) X(2, 4, 4, 2, 2, 4)
+// LN shapes (WM, WN, MTV, NTV, KB, STAGES, loader waves); lw code = 8 + loader waves (12 / 16).  Eight loaders (two per SIMD) let
+// one wave's norm VALU work run under the other's memory-issue stalls: the CU issues ~1 KiB of vector memory per 16-22 cycles,
+// a stage of a 128 x 128 tile is 32 pieces, and a wave that is stalled in issue cannot do VALU work of its own.
+#define GT_SHAPES_LN(X)                                                                                          \
+    X(2, 2, 4, 4, 2, 4, 8) X(2, 2, 4, 4, 2, 4, 4) X(2, 2, 2, 4, 2, 4, 4) X(2, 2, 4, 2, 2, 4, 8) X(2, 2, 4, 2, 2, 4, 4) \
+    X(2, 2, 2, 2, 4, 4, 4) X(4, 2, 2, 4, 2, 4, 8) X(2, 4, 4, 2, 2, 4, 8)
 
 template <typename D, int EPI, bool NORM>
 static int gt_dispatch(const GemmArgs& a, int wm, int wn, int mtv, int ntv, int kb, int stages, int lw, hipStream_t st) {
@@ -642,10 +658,10 @@ static int gt_dispatch(const GemmArgs& a, int wm, int wn, int mtv, int ntv, int 
     if constexpr (NORM) {
         GT_SHAPES_NORM(GT_CASE)
         // lw code 12: loader waves that normalise (LN), plain consumers with 2-D wave tiles
-#define GT_CASE_LN(WM_, WN_, MTV_, NTV_, KB_, ST_)                                                                    \
-    if (lw == 12 && wm == WM_ && wn == WN_ && mtv == MTV_ && ntv == NTV_ && kb == KB_ && stages == ST_) {            \
+#define GT_CASE_LN(WM_, WN_, MTV_, NTV_, KB_, ST_, NL_)                                                               \
+    if (lw == 8 + NL_ && wm == WM_ && wn == WN_ && mtv == MTV_ && ntv == NTV_ && kb == KB_ && stages == ST_) {         \
         if constexpr (EPI == EPI_SWIGLU && (NTV_ % 2)) return LGEN_ERR_UNSUPPORTED;                                    \
-        else return gt_launch<D, WM_, WN_, MTV_, NTV_, KB_, ST_, EPI, false, 4, true>(a, st);                           \
+        else return gt_launch<D, WM_, WN_, MTV_, NTV_, KB_, ST_, EPI, false, NL_, true>(a, st);                         \
     }
         GT_SHAPES_LN(GT_CASE_LN)
 #undef GT_CASE_LN

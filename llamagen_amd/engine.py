@@ -100,9 +100,13 @@ def tile_schedule_key(mts: int):
 # over k in order, whatever the tiling: tests/test_gpu_headline.py), so the search only ever changes the speed.
 TILE_SHAPES_NORM = ((4, 1, 1, 3, 4, 4, 4), (4, 1, 1, 4, 4, 4, 4), (4, 1, 1, 6, 2, 4, 4), (4, 1, 1, 6, 4, 3, 4), (4, 1, 1, 8, 2, 4, 4),
                     (4, 1, 2, 4, 2, 4, 4), (4, 1, 2, 6, 2, 4, 4), (4, 1, 2, 8, 2, 4, 4), (4, 1, 1, 2, 4, 4, 4), (8, 1, 1, 8, 2, 4, 4),
-                    (8, 1, 1, 6, 2, 4, 4), (8, 1, 1, 4, 2, 4, 4))
+                    (8, 1, 1, 6, 2, 4, 4), (8, 1, 1, 4, 2, 4, 4),
+                    (4, 1, 1, 8, 2, 6, 4), (4, 1, 1, 8, 2, 5, 4),   # deeper rings (contended regime)
+                    # lw codes 12 / 16: four / eight loader waves that normalise, plain consumers with 2-D wave tiles (round-5 candidate)
+                    (2, 2, 4, 4, 2, 4, 16), (2, 2, 4, 4, 2, 4, 12), (2, 2, 2, 4, 2, 4, 12), (2, 2, 4, 2, 2, 4, 16), (2, 2, 4, 2, 2, 4, 12), (2, 2, 2, 2, 4, 4, 12),
+                    (4, 2, 2, 4, 2, 4, 16), (2, 4, 4, 2, 2, 4, 16))
 TILE_SHAPES_PLAIN = ((2, 2, 1, 1, 4, 4, 4), (2, 2, 1, 2, 4, 4, 4), (2, 2, 2, 1, 4, 4, 4), (2, 2, 2, 2, 4, 4, 4), (2, 2, 2, 2, 2, 4, 4),
-                     (4, 1, 1, 2, 4, 4, 4), (2, 2, 4, 1, 4, 4, 4), (2, 2, 4, 2, 2, 4, 4))
+                     (4, 1, 1, 2, 4, 4, 4), (2, 2, 4, 1, 4, 4, 4), (2, 2, 4, 2, 2, 4, 4), (2, 2, 2, 2, 2, 9, 4), (2, 2, 2, 2, 2, 6, 4))
 TABLE_MODEL = (1024, 2816, 16384)   # (dim, ffn hidden, vocab) of GPT-L: the model TILE_SCHEDULES was measured on
 _TUNED = {}   # (device index, dim, F, V, n_head, MTs, per-row positions?) -> {kind: shape | None}: one search per process, shared by every lane
 

@@ -67,7 +67,10 @@ def plan_schedule(args, B, N, T):
     if args.batches_per_chain > 0:
         bpc = args.batches_per_chain
     elif args.config == 2:
-        bpc = max(1, min(12, (args.steps + 1) // 2))   # <= 768 rows: the tile shapes tests/test_gpu_headline.py holds to the oracle
+        # chain widths an end-to-end oracle test names (tests/test_gpu_headline.py): up to 6 batches (<= 384 rows: skinny kernels
+        # below 256 rows, TILE_SCHEDULES[16] from there) and 10 batches (640 rows, TILE_SCHEDULES[40]); 7..9 fall back to 6
+        want = max(1, min(10, (args.steps + 1) // 2))
+        bpc = want if (want <= 6 or want == 10) else 6
     elif args.config == 3:
         # GPT-XXL: two chains of up to six batches (384 rows) -- 42.0 img/s against 39.2 for three chains of four (round 4, same box
         # class, profiles/r04_bench_config3.json); 2 x 6 x (10.6 GB of KV + 1.2 GB of noise) = 142 GB resident
@@ -381,8 +384,9 @@ def cpu_baseline(steps=16, budget_s=30.0, with_c1=True):
     t_vq = (time.time() - t0) / 2
     per_batch = 0.5 * (t_early + t_late) * N + BATCH * t_vq
     impl = "reference modules (/root/reference, torch CPU)" if kind == "reference" else "oracle port (oracle/llamagen_oracle.py; no /root/reference on this box)"
-    out = {"value": round(BATCH / per_batch, 5), "unit": "images/s (B=32 slice, extrapolated)", "cores": best_thr,
-           "logical_cores": ncpu, "kind": kind, "impl": impl, "thread_sweep_ms_per_step_min_of_3": sweep,
+    out = {"value": round(BATCH / per_batch, 5), "unit": "images/s (B=32 slice, extrapolated)",
+           # `cores` is the contract's name for the THREADS the leg used (calibrated below), not the size of the host
+           "cores": best_thr, "threads": best_thr, "host_cores": ncpu, "logical_cores": ncpu, "kind": kind, "impl": impl, "thread_sweep_ms_per_step_min_of_3": sweep,
            "sample": f"{impl}, GPT-L 384px "
                      f"bf16 at B=32 (64 CFG rows), {best_thr} threads of {ncpu} logical cores: {steps} early + {steps} late "
                      f"decode steps ({t_early*1e3:.0f} / {t_late*1e3:.0f} ms per step) extrapolated linearly to 576 tokens, "
@@ -433,6 +437,34 @@ def live_traffic(rows, timeout_s=150):
         return vals
     except Exception:  # noqa: BLE001 -- timeout, missing csv, ...: fall back to the committed pass
         return None
+
+
+def other_configs(timeout_s=420):
+    """BASELINE configs 4 and 5 next to the headline: `bench.py --config N` (the schedule of profiles/r0x_bench_configN.json, fewer
+    steps) as a child process each, parsed from its JSON line.  A tested GEMM schedule is required there too (the child refuses an
+    untested one before timing).  Returns {"config4": {...}, "config5": {...}}; a failed pass is reported as such, never invented."""
+    out = {}
+    for c, steps, warm in ((4, 8, 2), (5, 12, 4)):
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", str(c), "--steps", str(steps), "--warmup", str(warm),
+               "--no-cpu-baseline", "--no-live-traffic", "--no-solo", "--no-one-chain", "--no-roofline"]
+        t0 = time.time()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            d = json.loads(line[-1]) if (r.returncode == 0 and line) else None
+        except Exception as ex:  # noqa: BLE001 -- timeout, bad JSON
+            d, r = None, None
+            err = repr(ex)
+        if d is None:
+            out[f"config{c}"] = {"error": (r.stderr[-300:] if r is not None else err), "seconds": round(time.time() - t0, 1)}
+            continue
+        out[f"config{c}"] = {"metric": d["metric"], "value": d["value"], "unit": d["unit"], "steps": d["steps"], "warmup": d["warmup"],
+                             "ms_per_step": d["ms_per_step"], "workload": d["config"]["workload"],
+                             "batches_per_chain": d["config"]["batches_per_chain"],
+                             "chains_in_flight_per_gpu": d["config"]["chains_in_flight_per_gpu"],
+                             "gemm_schedule": d.get("gemm_schedule"), "seconds": round(time.time() - t0, 1),
+                             "command": " ".join(cmd[1:])}
+    return out
 
 
 def _free_port():
@@ -510,6 +542,7 @@ def main():
     ap.add_argument("--budget-check-only", action="store_true", help="plan the schedule, check the per-GPU HBM budget, print it, exit")
     ap.add_argument("--allow-untested-schedule", action="store_true", help="run a GEMM schedule no end-to-end parity test names")
     ap.add_argument("--no-one-chain", action="store_true", help="skip the extra one-chain-in-flight leg (it needs another chain's KV slabs)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short passes of BASELINE configs 4 and 5 (default config-2 run)")
     ap.add_argument("--standin", action="store_true", help=argparse.SUPPRESS)  # CPU/gloo test of the launch path, see standin_main
     args = ap.parse_args()
 
@@ -566,6 +599,14 @@ def main():
                             vq_chunk=B if (bpc > 1 and args.lanes > 1) else 0)  # decode_code() batch by batch: finer interleaving
     pipe.prepare(B, N, **skw)  # setup (like loading weights): KV slabs, workspaces, decode graphs per lane
     torch.cuda.synchronize()
+    # The GEMM schedule the timed region is about to replay must be one an end-to-end oracle test names (tests/test_gpu_headline.py:
+    # the skinny kernels below 256 rows, a tested key of the model's pinned tile table from there).  Checked HERE, before anything is
+    # timed and on every rank alike (round 4 checked after the timed region, on rank 0 only: ADVICE r4).
+    eng0 = pipe.lanes[0].gpt._engine
+    gsched0, sched_tested, sched_source = eng0.gemm_schedule(), bool(eng0.tile_schedule_tested()), eng0.tile_schedule_source()
+    if not sched_tested and not args.allow_untested_schedule:
+        raise SystemExit(f"GEMM schedule {gsched0} (source: {sched_source}) is not one tests/test_gpu_headline.py holds to the oracle "
+                         "(--allow-untested-schedule to run it anyway)")
 
     from llamagen_amd.postprocess import to_uint8_hwc
 
@@ -639,7 +680,8 @@ def main():
                # SURVEY 8d closed form for ONE generate() of this config's batch (per GPU)
                "algorithmic_bytes_per_generate": {k: int(v) for k, v in phase.items()},
                # the same workload with ONE chain (bpc batches) in flight at a time (no cross-chain overlap)
-               "images_per_s_with_one_chain_in_flight": round(chain1, 3)}
+               "images_per_s_with_one_chain_in_flight": round(chain1, 3),
+               "gemm_schedule": {"schedule": gsched0, "source": sched_source, "tested_end_to_end": sched_tested}}
         total_b = sum(phase[k] for k in ("weights", "kv_reads", "kv_writes", "logits", "noise"))
         res["gpt_phase_floor_ms_per_step_at_8TBps"] = round(total_b / 8e12 * 1e3, 1)
         pmc = {}
@@ -663,14 +705,8 @@ def main():
                                "launch_us_by_position": per_pos}
             gm = measure_gemms(pipe.lanes[0].gpt)
             gsched = gm.pop("_schedule")
-            # the GEMM schedule the timed region replayed must be one an end-to-end oracle test names (tests/test_gpu_headline.py)
-            from llamagen_amd.engine import TESTED_TILE_SCHEDULES, TILE_SCHEDULES
-            tiles_run = {k: tuple(v_.get("shape(wm,wn,mtv,ntv,kb,stages,lw)", ())) for k, v_ in gsched.items()}
-            names = {"wqkv": "qkv", "wo": "wo", "w13": "w13", "w2": "w2", "lm_head": "head"}
-            tested = any(all(tiles_run[k] == TILE_SCHEDULES[m][names[k]] for k in tiles_run) for m in TESTED_TILE_SCHEDULES)
-            if args.config == 2 and not tested and not args.allow_untested_schedule:
-                raise SystemExit(f"GEMM schedule {gsched} is not one tests/test_gpu_headline.py holds to the oracle "
-                                 "(--allow-untested-schedule to run it anyway)")
+            assert gsched == gsched0, (gsched, gsched0)   # what this leg times is what the timed region replayed
+            tested = sched_tested
             nlay = gpt.config.n_layer
             tot_us = sum(us * (1 if k == "lm_head" else nlay) for k, (us, _) in gm.items())
             tot_b = sum(b * (1 if k == "lm_head" else nlay) for k, (_, b) in gm.items())
@@ -756,6 +792,13 @@ def main():
             solo.run([make_cond() for _ in range(2)], N, **skw)
             torch.cuda.synchronize()
             res["images_per_s_with_one_step_in_flight"] = round(B * 2 / (time.perf_counter() - t1), 3)
+        if world == 1 and args.config == 2 and not args.no_other_configs and not args.no_roofline:
+            # BASELINE configs 4 and 5 (GPT-3B 384 px batch 64; GPT-XL t2i 512 px batch 16) in the SAME driver run: one short pass
+            # each in a fresh process (own models, own HBM), after this process has released its decode state
+            pipe = None
+            gpt._engine = None
+            torch.cuda.empty_cache()
+            res["other_configs"] = other_configs()
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only (the other ranks would idle in the barrier)
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)

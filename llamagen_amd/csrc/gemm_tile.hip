@@ -45,16 +45,6 @@ LGEN_DEV u32x4_t gt_lds_rd(unsigned addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
     return v;
 }
-// register-path global load / LDS store of one lane's 16 bytes, invisible to the compiler's wait insertion like gt_lds_rd (LN loaders)
-LGEN_DEV u32x4_t gt_gload(const void* p) {
-    u32x4_t v;
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-template <int OFF>
-LGEN_DEV void gt_lds_wr(unsigned addr, const u32x4_t& v) {
-    asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
-}
 LGEN_DEV void gt_touch(u32x4_t& v) { asm volatile("" : "+v"(v)); }
 LGEN_DEV uint4 gt_u4(const u32x4_t& v) { return make_uint4(v[0], v[1], v[2], v[3]); }
 
@@ -117,14 +107,16 @@ struct QkvCol {
 // reads, RMSNorm, MFMA, epilogue) + LW loader waves (DMA issue and the counted waits only); a workgroup's waves are dealt to
 // the SIMDs round-robin, so every SIMD holds one consumer and one loader and the DMA issue overlaps the MFMA / VALU work.
 //
-// LN (round 5 candidate, shapes with lw code 12 = four / 16 = eight loader waves): the loader waves ALSO apply the RMSNorm.  They pull the activation
-// fragments of their row tiles through registers (asm `global_load_dwordx4`, a STAGES-deep register ring), normalise each
-// fragment ONCE per workgroup and `ds_write_b128` it into the ring slot as the finished MFMA operand; the weights keep the DMA
-// path.  The consumers then are the plain ones (no norm VALU, no norm-weight read) and can take 2-D wave tiles (64 x 64: 8
-// LDS reads per 16 MFMAs instead of 9 per 8), which the consumer-side norm could not afford (every N-wave would repeat it).
-template <typename D, int WM, int WN, int MTV, int NTV, int KB, int STAGES, int EPI, bool NORM, int LW, bool LN = false>
+// Measured and dropped in round 5 (profiles/r05_first_ab.log, r05_tile_sweep_640_ln_touch.log; code in git history, commit "Merge
+// branch r5-prep"): (a) loader waves that ALSO apply the RMSNorm (activation fragments through registers, normalised once per
+// workgroup, ds_write into the ring; plain consumers with 64 x 64 wave tiles = half the LDS reads per MFMA): bit-identical, no
+// faster alone (w1||w3 19.6 against 17.9 us, lm_head 55.5 against 51.5) and 107 against 122 img/s in the bench -- the K loop is not
+// bound by its LDS reads; (b) an L2 "touch-ahead" (one dword load per 128-byte line of the later stages right behind the first
+// ring stages): every touch pulls its line through the CU's vector L1, the same path the DMA pieces take, so the feed traffic
+// doubles -- wo 6.7 -> 9.8 us, w2 10.5 -> 15.6, w1||w3 17.9 -> 23.2, bench 112 against 122 img/s.  What that says: these kernels
+// are bound by the L2 -> CU feed (~45 B/clk/CU by LDS-DMA), i.e. by tile perimeter x K bytes per CU, not by LDS reads or MFMA.
+template <typename D, int WM, int WN, int MTV, int NTV, int KB, int STAGES, int EPI, bool NORM, int LW>
 __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_tile_kernel(GemmArgs a) {
-    static_assert(!LN || ((LW == 4 || LW == 8) && !NORM), "LN: four or eight loader waves normalise, the consumers are the plain ones");
     constexpr int NC = WM * WN, NL = LW ? LW : NC, MTW = WM * MTV, NTW = WN * NTV;
     constexpr int CPK = MTW + NTW;      // 1 KiB chunks per k-chunk of the workgroup tile
     constexpr int CPS = KB * CPK;       // chunks per ring stage
@@ -167,118 +159,6 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_tile_kernel(GemmArgs
         else gt_wait_vm<0>();
     };
 
-    if constexpr (LN) {
-        if (!consumer) {
-            // ================= loader wave that normalises (LN) =================
-            static_assert(MTW % NL == 0 && (KB * NTW) % NL == 0, "LN: whole row tiles / weight pieces per loader wave");
-            static_assert(STAGES == 4, "LN: the counted waits below are written out for a four-slot ring");
-            constexpr int RT = MTW / NL;            // row tiles of this loader wave
-            constexpr int FB = KB * RT;             // activation fragments per stage (register path)
-            constexpr int XG = FB;                  // vm operations of one stage's register group
-            constexpr int PA = KB * NTW / NL;       // weight pieces per stage (DMA path)
-            static_assert(3 * (XG + PA) <= 60, "vmcnt is a 6-bit counter");
-            const int r = lane & 15, g = lane >> 4;
-            // row scales of this wave's row tiles, statistics straight from global memory in the fixed order (as a.passes == 3)
-            float ri[RT];
-#pragma unroll
-            for (int t = 0; t < RT; ++t) {
-                float sum = gt_row_ssq_global(a.ssq_in + (size_t)((mt0 + lw * RT + t) * 16 + r) * LGEN_SSQ_STRIDE, a.parts, g);
-                sum += __shfl_xor(sum, 16, 64);
-                sum += __shfl_xor(sum, 32, 64);
-                ri[t] = 1.0f / sqrtf(sum * a.inv_k + a.eps);
-            }
-            // norm weight -> LDS behind the ring (every loader wave writes the same bytes and waits for its own copy: no barrier)
-            {
-                const int nwb = a.KCH * D::KC * D::ESZ;
-                for (int o = 0; o < nwb; o += 1024) {
-                    int off = o + lane * 16;
-                    off = off < nwb - 16 ? off : nwb - 16;
-                    __builtin_amdgcn_global_load_lds((gt_gptr_t)((const char*)a.nw + off), (gt_lptr_t)(smem + STAGES * STAGE_B + o), 16, 0, 0);
-                }
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing of the prologue stays in the counted window below
-            const unsigned ldsN = lds0 + STAGES * STAGE_B + g * 16;
-            // register ring: X[set][kk * RT + t] raw fragments of stage s in set s % STAGES
-            u32x4_t X[STAGES][FB];
-            const uint4* xsrc = a.xp + ((size_t)0 * a.MTs + mt0 + lw * RT) * 64 + lane;   // + (kchunk * MTs + t) * 64
-            auto xload = [&](auto set_, int s) {   // stage s -> register set
-                constexpr int SET = decltype(set_)::value;
-                gt_static_for<0, KB>([&](auto kk_) {
-                    constexpr int KK = decltype(kk_)::value;
-                    const uint4* px = xsrc + (size_t)(s * KB + KK) * a.MTs * 64;
-                    gt_static_for<0, RT>([&](auto t_) {
-                        constexpr int T = decltype(t_)::value;
-                        X[SET][KK * RT + T] = gt_gload(px + T * 64);
-                    });
-                });
-            };
-            const uint4* asrc[PA];
-#pragma unroll
-            for (int p = 0; p < PA; ++p) {
-                const int c = lw + p * NL, kk = c / NTW;
-                int nt = nt0 + (c - kk * NTW);
-                nt = nt < ntiles ? nt : ntiles - 1;   // ragged last n-group: re-reads a valid tile, its epilogue is skipped
-                asrc[p] = a.wp + ((size_t)nt * a.KCH + kk) * 64 + lane;
-            }
-            auto issueA = [&](int slot) {   // weight pieces of the next stage (sources advance by one stage per call)
-#pragma unroll
-                for (int p = 0; p < PA; ++p) {
-                    const int c = lw + p * NL, kk = c / NTW, n = c - kk * NTW;
-                    __builtin_amdgcn_global_load_lds((gt_gptr_t)asrc[p], (gt_lptr_t)(smem + slot * STAGE_B + (kk * CPK + MTW + n) * 1024), 16, 0, 0);
-                    asrc[p] += KB * 64;
-                }
-            };
-            auto put = [&](auto set_, int slot, int s) {   // normalise register set (stage s) -> ring slot, visible after the next barrier
-                constexpr int SET = decltype(set_)::value;
-                const unsigned base = lds0 + slot * STAGE_B + (lw * RT) * 1024 + lane * 16;
-                u32x4_t Wv[KB];
-                gt_static_for<0, KB>([&](auto kk_) { Wv[decltype(kk_)::value] = gt_lds_rd<decltype(kk_)::value * 64>(ldsN + (unsigned)(s * KB) * 64); });
-                gt_wait_lgkm<0>();
-                gt_static_for<0, KB>([&](auto kk_) {
-                    constexpr int KK = decltype(kk_)::value;
-                    gt_touch(Wv[KK]);
-                    const uint4 wn4 = gt_u4(Wv[KK]);
-                    gt_static_for<0, RT>([&](auto t_) {
-                        constexpr int T = decltype(t_)::value;
-                        gt_touch(X[SET][KK * RT + T]);
-                        const uint4 nb = D::norm_chunk(gt_u4(X[SET][KK * RT + T]), ri[T], wn4);
-                        const u32x4_t nv = {nb.x, nb.y, nb.z, nb.w};
-                        gt_lds_wr<(KK * CPK + T) * 1024>(base, nv);
-                    });
-                });
-                gt_wait_lgkm<0>();
-            };
-            // request order: x(0) x(1) A(0) x(2) A(1) ... x(STAGES-1) A(STAGES-2); steady state per iteration: x(it+STAGES) A(it+STAGES-1).
-            // x(s+1) is always OLDER than A(s): the wait that covers A(it) at the top of iteration it covers x(it+1) as well.
-            gt_static_for<0, STAGES>([&](auto s_) {
-                constexpr int S = decltype(s_)::value;
-                xload(s_, S);                                  // (launcher: NI >= STAGES)
-                if constexpr (S >= 1) issueA(S - 1);
-            });
-            gt_wait_vm<(STAGES - 1) * (XG + PA)>();            // x(0) landed
-            put(std::integral_constant<int, 0>{}, 0, 0);
-            for (int it0 = 0; it0 < NI; it0 += STAGES) {
-                gt_static_for<0, STAGES>([&](auto r_) {
-                    constexpr int R = decltype(r_)::value;
-                    const int it = it0 + R;
-                    if (it < NI) {
-                        // A(it) landed (and with it x(it+1)): the requests younger than A(it) are x(it+2) A(it+1) x(it+3) A(it+2)
-                        const int rem = NI - 1 - it;
-                        if (rem >= 3) gt_wait_vm<2 * (XG + PA)>();
-                        else if (rem == 2) gt_wait_vm<XG + 2 * PA>();
-                        else if (rem == 1) gt_wait_vm<PA>();
-                        else gt_wait_vm<0>();
-                        __builtin_amdgcn_s_barrier();
-                        asm volatile("" ::: "memory");
-                        if (it + STAGES < NI) xload(r_, it + STAGES);                                       // into the set x(it) left
-                        if (it + STAGES - 1 < NI) issueA((R + STAGES - 1) % STAGES);                        // the slot stage it-1 left
-                        if (it + 1 < NI) put(std::integral_constant<int, (R + 1) % STAGES>{}, (R + 1) % STAGES, it + 1);
-                    }
-                });
-            }
-            return;
-        }
-    }
     if (LW != 0 && !consumer) {
         // ================= loader wave =================
         const uint4* src[P];
@@ -580,14 +460,12 @@ static int gt_xr_override() {   // development switch LGEN_TILE_XR=0|1|2: log2 o
 }
 
 // ---- launch table ---------------------------------------------------------------------------------------------------------
-template <typename D, int WM, int WN, int MTV, int NTV, int KB, int STAGES, int EPI, bool NORM, int LW, bool LN = false>
+template <typename D, int WM, int WN, int MTV, int NTV, int KB, int STAGES, int EPI, bool NORM, int LW>
 static int gt_launch(const GemmArgs& a_in, hipStream_t st) {
     GemmArgs a = a_in;
     constexpr int NW = WM * WN, MTW = WM * MTV, NTW = WN * NTV, CPS = KB * (MTW + NTW), STAGE_B = CPS * 1024;
     if (a.MTs % MTW || a.KCH % KB || a.KCH / KB < STAGES - 1) return LGEN_ERR_UNSUPPORTED;
-    if (LN && a.KCH / KB < STAGES) return LGEN_ERR_UNSUPPORTED;
     size_t lds = (size_t)STAGES * STAGE_B;
-    if (LN) lds += ((size_t)a.KCH * D::KC * D::ESZ + 1023) / 1024 * 1024;   // the norm weight behind the ring (read by the loader waves)
     a.passes = 1;
     if (NORM) {
         if (a.parts % 4) return LGEN_ERR_UNSUPPORTED;
@@ -602,10 +480,15 @@ static int gt_launch(const GemmArgs& a_in, hipStream_t st) {
     if (lds > 160 * 1024) return LGEN_ERR_UNSUPPORTED;
     const int ntiles = a.N / 16;
     const int gx = (ntiles + NTW - 1) / NTW, gy = a.MTs / MTW;
-    auto kern = gemm_tile_kernel<D, WM, WN, MTV, NTV, KB, STAGES, EPI, NORM, LW, LN>;
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
+    auto kern = gemm_tile_kernel<D, WM, WN, MTV, NTV, KB, STAGES, EPI, NORM, LW>;
+    if (lds > 64 * 1024) {   // once per (instantiation, device): the most this kernel ever asks for
+        static unsigned long long attr_set_mask = 0;
+        const int dev_i = lgen_cur_dev();
+        if (!((attr_set_mask >> dev_i) & 1)) {
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return (int)e;
+            attr_set_mask |= 1ull << dev_i;
+        }
     }
     // rows split over XR groups of XCDs (see the block-id decode in the kernel): the balanced split with the fewest L2 fills
     int xrl = gt_xr_override();
@@ -621,7 +504,7 @@ static int gt_launch(const GemmArgs& a_in, hipStream_t st) {
     } else if (gy % (1 << xrl)) {
         xrl = 0;
     }
-    a.db = (a.db & 0xff) | (xrl << 8);
+    a.db = (a.db & ~0x300) | (xrl << 8);
     const int XR = 1 << xrl, XC = 8 >> xrl;
     hipLaunchKernelGGL(kern, dim3(8 * ((gx + XC - 1) / XC) * ((gy + XR - 1) / XR)), dim3(64 * (NW + LW)), lds, st, a);
     LGEN_CHECK_LAUNCH();
@@ -633,19 +516,12 @@ static int gt_launch(const GemmArgs& a_in, hipStream_t st) {
     X(4, 1, 1, 3, 4, 4, 4) X(4, 1, 1, 4, 4, 4, 4) X(4, 1, 1, 6, 2, 4, 4) X(4, 1, 1, 6, 4, 3, 4) X(4, 1, 1, 8, 2, 4, 4) \
     X(4, 1, 2, 4, 2, 4, 4) X(4, 1, 2, 6, 2, 4, 4) X(4, 1, 2, 8, 2, 4, 4) X(4, 1, 1, 2, 4, 4, 4) X(4, 1, 1, 3, 4, 4, 0) \
     X(8, 1, 1, 8, 2, 4, 4) X(8, 1, 1, 6, 2, 4, 4) X(8, 1, 1, 4, 2, 4, 4)                                          \
-    /* deeper rings (round-5 candidates: more operand bytes in flight per CU for the contended regime) */ \
+    /* deeper rings (round 5: more operand bytes in flight per CU for the contended regime; 122.9 against 121.6 img/s in one bench A/B) */ \
     X(4, 1, 1, 8, 2, 6, 4) X(4, 1, 1, 8, 2, 5, 4)
 #define GT_SHAPES_PLAIN(X)                                                                                       \
     X(2, 2, 1, 1, 4, 4, 4) X(2, 2, 1, 2, 4, 4, 4) X(2, 2, 2, 1, 4, 4, 4) X(2, 2, 2, 2, 4, 4, 4) X(2, 2, 2, 2, 2, 4, 4) \
     X(4, 1, 1, 2, 4, 4, 4) X(2, 2, 1, 1, 4, 4, 0) X(2, 2, 4, 1, 4, 4, 4) X(2, 2, 4, 2, 2, 4, 4)                   \
     X(2, 2, 2, 2, 2, 9, 4) X(2, 2, 2, 2, 2, 6, 4)
-
-// LN shapes (WM, WN, MTV, NTV, KB, STAGES, loader waves); lw code = 8 + loader waves (12 / 16).  Eight loaders (two per SIMD) let
-// one wave's norm VALU work run under the other's memory-issue stalls: the CU issues ~1 KiB of vector memory per 16-22 cycles,
-// a stage of a 128 x 128 tile is 32 pieces, and a wave that is stalled in issue cannot do VALU work of its own.
-#define GT_SHAPES_LN(X)                                                                                          \
-    X(2, 2, 4, 4, 2, 4, 8) X(2, 2, 4, 4, 2, 4, 4) X(2, 2, 2, 4, 2, 4, 4) X(2, 2, 4, 2, 2, 4, 8) X(2, 2, 4, 2, 2, 4, 4) \
-    X(2, 2, 2, 2, 4, 4, 4) X(4, 2, 2, 4, 2, 4, 8) X(2, 4, 4, 2, 2, 4, 8)
 
 template <typename D, int EPI, bool NORM>
 static int gt_dispatch(const GemmArgs& a, int wm, int wn, int mtv, int ntv, int kb, int stages, int lw, hipStream_t st) {
@@ -657,14 +533,6 @@ static int gt_dispatch(const GemmArgs& a, int wm, int wn, int mtv, int ntv, int 
     }
     if constexpr (NORM) {
         GT_SHAPES_NORM(GT_CASE)
-        // lw code 12: loader waves that normalise (LN), plain consumers with 2-D wave tiles
-#define GT_CASE_LN(WM_, WN_, MTV_, NTV_, KB_, ST_, NL_)                                                               \
-    if (lw == 8 + NL_ && wm == WM_ && wn == WN_ && mtv == MTV_ && ntv == NTV_ && kb == KB_ && stages == ST_) {         \
-        if constexpr (EPI == EPI_SWIGLU && (NTV_ % 2)) return LGEN_ERR_UNSUPPORTED;                                    \
-        else return gt_launch<D, WM_, WN_, MTV_, NTV_, KB_, ST_, EPI, false, NL_, true>(a, st);                         \
-    }
-        GT_SHAPES_LN(GT_CASE_LN)
-#undef GT_CASE_LN
     } else {
         GT_SHAPES_PLAIN(GT_CASE)
     }
@@ -674,7 +542,7 @@ static int gt_dispatch(const GemmArgs& a, int wm, int wn, int mtv, int ntv, int 
 
 static int gt_ablate() {   // development switch: bit 0 no RMSNorm VALU work, bit 1 no LDS reads / MFMAs, bit 2 no operand DMA, bit 3 no epilogue, bit 4 no statistics prologue
     const char* e = getenv("LGEN_TILE_ABLATE");
-    return e ? atoi(e) : 0;
+    return (e ? atoi(e) : 0) & 0xff;
 }
 
 static int gt_dispatch_epi(const GemmArgs& a, int epi, int wm, int wn, int mtv, int ntv, int kb, int stages, int lw, hipStream_t st) {

@@ -541,12 +541,7 @@ static int attn_decode_impl(const void* q, const void* k_cache, const void* v_ca
         // persistent form, (K/V loads per buffer CH, waves per workgroup) = 8: (4, 8), one workgroup per CU; 9: (4, 8) x two per CU;
         // 10: (4, 4); 11: (2, 8); 12: (2, 4); 13: (1, 8).  Bytes in flight per CU = waves x 4 x CH KiB: what the HBM queue holds
         // beyond the bandwidth-delay product (~10 MB chip-wide) only adds latency for every kernel that shares the chip.
-        static int n_cu = 0;
-        if (!n_cu) {
-            int dev = 0, v = 0;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 256;
-            n_cu = v > 0 ? v : 256;
-        }
+        const int n_cu = lgen_cu_count();
         const int items = B2 * n_head;
         const int nwv = (variant == 10 || variant == 12 || variant == 14) ? 4 : 8;
         const int ch = variant == 14 ? 3 : (variant <= 10 ? 4 : (variant <= 12 ? 2 : 1));

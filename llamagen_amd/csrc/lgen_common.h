@@ -274,4 +274,21 @@ LGEN_DEV float across_groups(float v, F&& op) {
     return v;
 }
 
+// Per-device one-time state of the launchers (kernel attributes, CU count): the deployment is one process per GPU, but nothing in
+// the ABI stops a caller from switching devices, and a function attribute set on one device says nothing about another.
+static inline int lgen_cur_dev() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) d = 0;
+    return d & 63;
+}
+static inline int lgen_cu_count() {
+    static int n_cu[64] = {0};
+    const int d = lgen_cur_dev();
+    if (!n_cu[d]) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess) v = 256;
+        n_cu[d] = v > 0 ? v : 256;
+    }
+    return n_cu[d];
+}
 #define LGEN_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)

@@ -470,6 +470,9 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(SampleArgs a) {
         int bi = red_i[0];
         for (int i = 1; i < SMP_THREADS / 64; ++i)
             if (red_f[i] > bb || (red_f[i] == bb && red_i[i] < bi)) { bb = red_f[i]; bi = red_i[i]; }
+        // a row whose every ratio is NaN (non-finite logits or noise, e.g. a filler row fed uninitialised memory) has no maximum:
+        // token 0 instead of the 0x7fffffff sentinel, which the next step's embedding lookup would follow out of bounds
+        bi = (unsigned)bi < (unsigned)a.V ? bi : 0;
         a.cur_tok[b] = bi;
         if (a.use_cfg) a.cur_tok[B + b] = bi;
         a.seq[(size_t)b * a.seq_stride + step] = bi;
@@ -497,8 +500,9 @@ static int sample_impl(const void* logits, const float* noise, long long noise_s
                  temperature, top_p, cfg_interval, top_k, greedy, row_step, row_pos, max_steps};
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = (size_t)SMP_MAXV * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {  // row (64 KiB) + small statics exceeds the default 64 KiB LDS cap
+    static unsigned long long attr_set_mask = 0;   // per device
+    const int dev_i = lgen_cur_dev();
+    if (!((attr_set_mask >> dev_i) & 1)) {  // row (64 KiB) + small statics exceeds the default 64 KiB LDS cap
         hipError_t e1 = hipFuncSetAttribute((const void*)sample_kernel<BF16>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             SMP_MAXV * (int)sizeof(float));
         hipError_t e2 = hipFuncSetAttribute((const void*)sample_kernel<F32>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -508,7 +512,7 @@ static int sample_impl(const void* logits, const float* noise, long long noise_s
         if (e3 != hipSuccess) return (int)e3;
         if (e1 != hipSuccess) return (int)e1;
         if (e2 != hipSuccess) return (int)e2;
-        attr_set = true;
+        attr_set_mask |= 1ull << dev_i;
     }
     if (dtype == LGEN_BF16)
         hipLaunchKernelGGL(sample_kernel<BF16>, dim3(B), dim3(SMP_THREADS), lds, st, a);

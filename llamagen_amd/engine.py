@@ -85,29 +85,47 @@ TILE_SCHEDULES = {
 }
 TILE_SCHEDULE_EXACT = (40,)        # keys that serve exactly that MTs; the others serve every MTs from the key up to the next one
 TESTED_TILE_SCHEDULES = (16, 40)   # keys of TILE_SCHEDULES with an end-to-end oracle test (tests/test_gpu_headline.py)
+TABLE_MODEL = (1024, 2816, 16384)   # (dim, ffn hidden, vocab) of GPT-L: the model TILE_SCHEDULES was measured on
+
+# The other registry models that bench.py runs with chains of >= 256 rows: the shapes the round-4 on-device search settled on
+# (profiles/r04_bench_config{3,4}.json, `schedule`), now PINNED.  Round 4 timed every shape (and the skinny kernel) at first use in
+# the user's process and kept whichever was faster at that moment: the tile shapes agree bit for bit, but tile and skinny differ in
+# accumulation order and in the SwiGLU's exp / reciprocal, so the family -- and with it bf16 logits -- depended on timing noise
+# (ADVICE round 4).  The family now depends on shapes only: tile wherever a table names a shape the library takes.
+MODEL_TILE_SCHEDULES = {
+    TABLE_MODEL: TILE_SCHEDULES,
+    (1536, 4096, 16384): {   # GPT-XXL (config 3: two chains of six batches = 384 rows)
+        16: {"qkv": (4, 1, 1, 8, 2, 4, 4), "wo": (2, 2, 2, 2, 4, 4, 4), "w13": (4, 1, 2, 8, 2, 4, 4), "w2": (2, 2, 2, 2, 4, 4, 4),
+             "head": (4, 1, 2, 8, 2, 4, 4)}},
+    (3200, 8704, 16384): {   # GPT-3B (config 4: two chains of two batches of 64 = 256 rows)
+        16: {"qkv": (8, 1, 1, 6, 2, 4, 4), "wo": (2, 2, 2, 2, 4, 4, 4), "w13": (4, 1, 1, 6, 2, 4, 4), "w2": (2, 2, 2, 2, 4, 4, 4),
+             "head": (8, 1, 1, 8, 2, 4, 4)}},
+}
+# (dim, F, V) -> keys of its table that an end-to-end oracle test runs (test_config{3,4}_..._shapes_bf16_vs_oracle[128]: 256-row chains)
+TESTED_MODEL_SCHEDULES = {TABLE_MODEL: TESTED_TILE_SCHEDULES, (1536, 4096, 16384): (16,), (3200, 8704, 16384): (16,)}
 
 
-def tile_schedule_key(mts: int):
-    """Key of TILE_SCHEDULES that serves a chain of `mts` m-tiles (None: below 256 rows, the skinny kernels)."""
-    if mts in TILE_SCHEDULE_EXACT:
+def tile_schedule_key(mts: int, table=None):
+    """Key of a tile table (default TILE_SCHEDULES) that serves a chain of `mts` m-tiles (None: below 256 rows, the skinny kernels)."""
+    table = TILE_SCHEDULES if table is None else table
+    exact = TILE_SCHEDULE_EXACT if table is TILE_SCHEDULES else ()
+    if mts in exact:
         return mts
-    keys = [k for k in TILE_SCHEDULES if k not in TILE_SCHEDULE_EXACT and k <= mts]
+    keys = [k for k in table if k not in exact and k <= mts]
     return max(keys) if keys else None
 
 
-# Every workgroup shape the library instantiates (csrc/gemm_tile.hip GT_SHAPES_NORM / GT_SHAPES_PLAIN): the candidates of the
-# on-device shape search below.  All shapes of the family produce bit-identical results (one wave accumulates an output element
-# over k in order, whatever the tiling: tests/test_gpu_headline.py), so the search only ever changes the speed.
+# Every workgroup shape the library instantiates (csrc/gemm_tile.hip GT_SHAPES_NORM / GT_SHAPES_PLAIN / GT_SHAPES_LN): the candidates
+# of the opt-in on-device shape search below (LGEN_TILE_AUTOTUNE=1).  All shapes of the family produce bit-identical results (one
+# wave accumulates an output element over k in order, whatever the tiling: tests/test_gpu_headline.py), and the search never leaves
+# the family, so it only ever changes the speed.
 TILE_SHAPES_NORM = ((4, 1, 1, 3, 4, 4, 4), (4, 1, 1, 4, 4, 4, 4), (4, 1, 1, 6, 2, 4, 4), (4, 1, 1, 6, 4, 3, 4), (4, 1, 1, 8, 2, 4, 4),
                     (4, 1, 2, 4, 2, 4, 4), (4, 1, 2, 6, 2, 4, 4), (4, 1, 2, 8, 2, 4, 4), (4, 1, 1, 2, 4, 4, 4), (8, 1, 1, 8, 2, 4, 4),
                     (8, 1, 1, 6, 2, 4, 4), (8, 1, 1, 4, 2, 4, 4),
-                    (4, 1, 1, 8, 2, 6, 4), (4, 1, 1, 8, 2, 5, 4),   # deeper rings (contended regime)
-                    # lw codes 12 / 16: four / eight loader waves that normalise, plain consumers with 2-D wave tiles (round-5 candidate)
-                    (2, 2, 4, 4, 2, 4, 16), (2, 2, 4, 4, 2, 4, 12), (2, 2, 2, 4, 2, 4, 12), (2, 2, 4, 2, 2, 4, 16), (2, 2, 4, 2, 2, 4, 12), (2, 2, 2, 2, 4, 4, 12),
-                    (4, 2, 2, 4, 2, 4, 16), (2, 4, 4, 2, 2, 4, 16))
+                    (4, 1, 1, 8, 2, 6, 4), (4, 1, 1, 8, 2, 5, 4)   # deeper rings (contended regime)
+)
 TILE_SHAPES_PLAIN = ((2, 2, 1, 1, 4, 4, 4), (2, 2, 1, 2, 4, 4, 4), (2, 2, 2, 1, 4, 4, 4), (2, 2, 2, 2, 4, 4, 4), (2, 2, 2, 2, 2, 4, 4),
                      (4, 1, 1, 2, 4, 4, 4), (2, 2, 4, 1, 4, 4, 4), (2, 2, 4, 2, 2, 4, 4), (2, 2, 2, 2, 2, 9, 4), (2, 2, 2, 2, 2, 6, 4))
-TABLE_MODEL = (1024, 2816, 16384)   # (dim, ffn hidden, vocab) of GPT-L: the model TILE_SCHEDULES was measured on
 _TUNED = {}   # (device index, dim, F, V, n_head, MTs, per-row positions?) -> {kind: shape | None}: one search per process, shared by every lane
 
 
@@ -235,12 +253,14 @@ class DecodeEngine:
         kch = self.d // self.kc
         auto = dtype == torch.bfloat16 and kch % 8 == 0 and 3 <= kch // 8 <= 6
         self.use_tile = os.environ.get("LGEN_GEMM_TILE", "1") != "0"
-        self.tile_autotune = os.environ.get("LGEN_TILE_AUTOTUNE", "1") != "0"
+        self.tile_autotune = os.environ.get("LGEN_TILE_AUTOTUNE", "0") == "1"   # opt-in (development): time the tile shapes on the device
         # (round 4) the big-M tile family normalises the B fragments between LDS and the MFMA, whatever the row length: chains of
         # >= 256 rows fuse for every width whose statistics row the kernels take (GPT-3B: d = 3200, 200 partials per row)
+        self._fuse_base = auto   # what holds without the tile family (per-row positions: the wqkv of a continuous batcher stays skinny)
         if dtype == torch.bfloat16 and self.MTs >= 16 and self.use_tile and (self.d // 16) % 4 == 0 and self.d // 16 <= L.SSQ_STRIDE:
             auto = True
         env = os.environ.get("LGEN_FUSED_NORM")
+        self._fuse_env = env
         self.fuse_norm = auto if env is None else env == "1"
         self.tile_override = {}      # kind ("qkv" | "wo" | "w13" | "w2" | "head") -> (mt, nt, kw)
         # tuning hook: LGEN_TILES="qkv=2,4,8;wo=4,1,8;w2=4,1,8" (e.g. fewer, fatter workgroups per GEMM so that the
@@ -274,6 +294,20 @@ class DecodeEngine:
                 raise ValueError(f"LGEN_PASSES: '{item}' is not kind=passes,double_buffer")
             self.pass_override[kind.strip()] = t
         self._pack(model)
+
+    @property
+    def pos_rows(self):
+        return self._pos_rows
+
+    @pos_rows.setter
+    def pos_rows(self, value):
+        """Per-row positions (llamagen_amd/serve.py) keep wqkv on the skinny kernels, so the RMSNorm is fused only where the
+        register-resident fused-norm GEMMs apply (d / 32 = 8 x 3..6): a wide model (GPT-3B) that fused because its chain is >= 256
+        rows would otherwise run the generic norm-prologue kernel, slower than stand-alone norm + the wide ring shapes."""
+        self._pos_rows = value
+        if value is not None and getattr(self, "_fuse_env", None) is None and hasattr(self, "_fuse_base") and self.fuse_norm != self._fuse_base:
+            self.fuse_norm = self._fuse_base
+            self._graphs = {}
 
     # ---- weights --------------------------------------------------------------------------
     def _sig(self, model):
@@ -381,8 +415,9 @@ class DecodeEngine:
             tuned = self._tuned_shapes()
             if tuned is not None:
                 return tuned[kind]
-        key = tile_schedule_key(self.MTs)
-        return None if key is None else TILE_SCHEDULES[key][kind]
+        table = MODEL_TILE_SCHEDULES.get((self.d, self.F, self.V), TILE_SCHEDULES)   # unknown widths: GPT-L's shapes by chain width
+        key = tile_schedule_key(self.MTs, table)
+        return None if key is None else table[key][kind]
 
     # ---- on-device shape search (models / chain widths without a measured table) ---------------------------------------------
     def _tile_call(self, kind, w, i, s, x_in, nw):
@@ -411,10 +446,12 @@ class DecodeEngine:
         return _TUNED[key]
 
     def _search_tile_shapes(self):
-        """Times every instantiated workgroup shape of the tile family (and the skinny kernel) for each decode GEMM as a captured
-        pass over ALL layers' weights (nothing stays cache-resident from one launch to the next, as in the decode chain) and keeps
-        the fastest.  Runs on the engine's own workspaces, which it saves and restores; a few hundred launches, once per process
-        per (model width, chain width).  The result only changes speed: every shape gives the same bits."""
+        """Opt-in (LGEN_TILE_AUTOTUNE=1): times every instantiated workgroup shape of the tile family for each decode GEMM as a
+        captured pass over ALL layers' weights (nothing stays cache-resident from one launch to the next, as in the decode chain)
+        and keeps the fastest TILE shape; the skinny kernel is timed for the report only and is chosen only where the library takes
+        no tile shape at all -- the family never depends on a timing (tile and skinny differ in accumulation order).  Runs on the
+        engine's own workspaces, which it saves and restores; a few hundred launches, once per process per (model width, chain
+        width).  The result only changes speed: every tile shape gives the same bits."""
         keep = {n: getattr(self, n).clone() for n in ("hp", "ap", "gp", "qbuf", "ssq", "logits", "state")}
         pos = int(self.state[0])
         kv_keep = (self.k_cache[:, :, :, pos].clone(), self.v_cache[:, :, :, pos].clone())
@@ -488,8 +525,8 @@ class DecodeEngine:
                         return True
                     return run
 
-                best_t, best_s = timed(skinny), None
-                report[kind] = {"skinny": best_t}
+                best_t, best_s = float("inf"), None
+                report[kind] = {"skinny": timed(skinny)}
                 for s in shapes:
                     if self.MTs % (s[0] * s[2]) or (kind == "w13" and s[3] % 2):
                         continue
@@ -588,13 +625,30 @@ class DecodeEngine:
             raise ValueError(kind)
 
     def tile_schedule_source(self) -> str:
-        """Where the tile shapes of gemm_schedule() come from: "override" (LGEN_TILE_SHAPES), "table" (TILE_SCHEDULES, measured
-        for GPT-L), "search" (timed on this device at first use), or "none" (chains below 256 rows / other storage types)."""
+        """Where the tile shapes of gemm_schedule() come from: "override" (LGEN_TILE_SHAPES), "table" (MODEL_TILE_SCHEDULES: measured
+        and pinned per registry model), "table (GPT-L shapes by chain width)" (other widths), "search" (LGEN_TILE_AUTOTUNE=1: timed on
+        this device at first use), or "none" (chains below 256 rows / other storage types)."""
         if self.tile_shape_override:
             return "override"
         if not self.use_tile or self.MTs < 16 or self.dtype != torch.bfloat16 or not self.fuse_norm:
             return "none"
-        return "search" if (self.d, self.F, self.V) != TABLE_MODEL and self.tile_autotune else "table"
+        if (self.d, self.F, self.V) != TABLE_MODEL and self.tile_autotune:
+            return "search"
+        return "table" if (self.d, self.F, self.V) in MODEL_TILE_SCHEDULES else "table (GPT-L shapes by chain width)"
+
+    def tile_schedule_tested(self) -> bool:
+        """True when every GEMM of the decode graph runs a schedule an end-to-end oracle test names (tests/test_gpu_headline.py):
+        the skinny kernels (chains below 256 rows: the round-2/3 tests of every config) or a tested key of this model's tile table."""
+        sched = self.gemm_schedule()
+        if all(v["family"] == "skinny" for v in sched.values()):
+            return not self.tile_shape_override and not self.tile_override and not self.pass_override
+        model = (self.d, self.F, self.V)
+        table = MODEL_TILE_SCHEDULES.get(model)
+        if table is None or self.tile_schedule_source() != "table":
+            return False
+        names = {"wqkv": "qkv", "wo": "wo", "w13": "w13", "w2": "w2", "lm_head": "head"}
+        run = {k: tuple(v.get("shape(wm,wn,mtv,ntv,kb,stages,lw)", ())) for k, v in sched.items()}
+        return any(all(run[k] == table[m][names[k]] for k in run) for m in TESTED_MODEL_SCHEDULES.get(model, ()))
 
     def gemm_schedule(self) -> dict:
         """The kernel family and shapes the decode graph launches per GEMM kind (bench.py prints it; tests pin it)."""
@@ -798,7 +852,8 @@ class DecodeEngine:
     # ---- Exp(1) noise: what torch.multinomial draws, one [B, V] fp32 exponential_ per sampled token ----
     def _noise_buffer(self, N, B):
         if self.noise is None or self.noise.shape[0] < N or self.noise.shape[1] != B:
-            self.noise = torch.empty(N, B, self.V, dtype=torch.float32, device=self.dev)
+            # ones, not empty: the slice of a filler batch (generate.PadBatch) is never drawn, and the sampler divides by it
+            self.noise = torch.ones(N, B, self.V, dtype=torch.float32, device=self.dev)
         return self.noise
 
     def draw_noise(self, N, B, b0, n):

@@ -79,7 +79,7 @@ def generate_iter(model, cond, max_new_tokens, emb_masks=None, cfg_scale=1.0, cf
                     raise ValueError("batches that share a chain must have the same size")
                 parts.append(c_j)
                 mask_parts.append(m_j if m_j is not None else emb_masks)        # no own mask: the shared one (or none at all)
-            if sample_logits and not pad:   # (a filler's slice of the noise buffer keeps whatever it held: finite, unused)
+            if sample_logits and not pad:   # (a filler's slice keeps what it held: ones from the allocation or an earlier batch's draws -- positive, finite, its tokens are dropped)
                 model._engine.draw_noise(max_new_tokens, n * groups, j * n, n)
         cond = torch.cat(parts)
         if any(m is not None for m in mask_parts):

@@ -195,19 +195,226 @@ def test_config2_gptl_bf16_four_batches_per_chain_logits_vs_oracle():
 
 def test_config2_gptl_bf16_ten_batches_per_chain_logits_vs_oracle():
     """Round 4 schedule (`bench.py --steps 20`: two chains of ten batches): 640 rows, MTs = 40, every decode GEMM on the big-M tile
-    family with the 640-row shapes (one round of <= 256 workgroups per launch), persistent decode attention (>= 256 rows): prefill, position 1 and position 299 on injected
-    cache contents, same bar as the 64-row test; the schedule the bench prints (`roofline_gemm.schedule`) is pinned here."""
+    family with the 640-row shapes (one round of <= 256 workgroups per launch), persistent decode attention (>= 256 rows): prefill, position 1 and positions 299 / 574
+    (the last step of a generate(): the longest key stream of the persistent attention) on injected cache contents, same bar as the
+    64-row test; the schedule the bench prints (`roofline_gemm.schedule`) is pinned here."""
     case = dict(registry="GPT-L", kwargs=dict(vocab_size=16384, block_size=576, num_classes=1000, cls_token_num=1,
                                               model_type="c2i"), wseed=21, lin_std=0.02)
     B = 320
     cond = torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(6))
-    recs, m = _teacher_forced(case, B, 4.0, early=1, late=[299], cond=cond)
+    recs, m = _teacher_forced(case, B, 4.0, early=1, late=[299, 574], cond=cond)
     e = m._engine
     assert e.fuse_norm and e.MTs == 40 and e.S8 == 584
     sched = e.gemm_schedule()
     assert all(v["family"] == "tile" for v in sched.values()), sched
     assert _pinned(40) == {k: tuple(v["shape(wm,wn,mtv,ntv,kb,stages,lw)"]) for k, v in sched.items()}, sched
     _check("config2_gptl_b640", recs)
+
+
+GPTL_CASE = dict(registry="GPT-L", kwargs=dict(vocab_size=16384, block_size=576, num_classes=1000, cls_token_num=1,
+                                               model_type="c2i"), wseed=21, lin_std=0.02)
+
+
+def test_config2_640rows_graph_replay_equals_eager_launches_free_running_bf16():
+    """The timed configuration, end to end and free-running: ONE generate() of 320 images (ten batches of 32 = 640 CFG rows, the
+    chain shape of `bench.py --steps 20`), GPT-L bf16, all 576 tokens, cfg 4.0, top-k 2000, on the tile GEMMs + persistent
+    attention -- once as the product runs it (the captured decode-step hipGraph replayed 574 times, device-side position / step
+    counters) and once with every kernel launched eagerly (LGEN_NO_GRAPH=1), from the same Exp(1) draws.  Same kernels, same
+    operands: the two token streams must be IDENTICAL (a capture that froze a position, a pointer or a noise offset, or a replay
+    that raced the previous step, shows up as a difference somewhere in 320 x 576 tokens)."""
+    from llamagen_amd import generate
+    dev = _dev()
+    m, _ = build_gpt_holder(GPTL_CASE)
+    m = m.to(device=dev, dtype=torch.bfloat16)
+    B, N, V = 320, 576, 16384
+    cond = torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(8)).to(dev)
+    noise = torch.empty(N, B, V, device=dev)
+    g = torch.Generator(device=dev).manual_seed(1234)
+    for j in range(N):
+        noise[j].exponential_(1.0, generator=g)
+    kw = dict(cfg_scale=4.0, cfg_interval=-1, temperature=1.0, top_k=2000, top_p=1.0, sample_logits=True)
+    assert os.environ.get("LGEN_NO_GRAPH") is None
+    t_graph = generate(m, cond, N, _noise_seq=noise, **kw).cpu()
+    e = m._engine
+    assert e.MTs == 40 and e.S8 == 584 and len(e._graphs) == 1
+    sched = e.gemm_schedule()
+    assert _pinned(40) == {k: tuple(v["shape(wm,wn,mtv,ntv,kb,stages,lw)"]) for k, v in sched.items()}, sched
+    os.environ["LGEN_NO_GRAPH"] = "1"
+    try:
+        t_eager = generate(m, cond, N, _noise_seq=noise, **kw).cpu()
+    finally:
+        del os.environ["LGEN_NO_GRAPH"]
+    assert t_graph.shape == (B, N) and int(t_graph.min()) >= 0 and int(t_graph.max()) < V
+    same = (t_graph == t_eager)
+    assert bool(same.all()), (int((~same).sum()), int((~same).any(1).sum()), int((~same).float().argmax()))
+    assert len(torch.unique(t_graph)) > 1000   # a sampled stream, not a constant
+    _log("config2_b640_graph_vs_eager", dict(tokens=int(same.numel()), identical=True))
+
+
+def _rows_fill(eng, kb, vb, rows, pos, hd):
+    """K/V slots [0, pos) of every layer of engine `eng` <- rows `rows` of the [R, H, S8, hd] random blocks (layer-rolled as in
+    _fill_caches): the same cache contents for the same image whichever chain carries it."""
+    S8 = kb.shape[2]
+    for li in range(eng.L):
+        sh = (li * 37) % S8
+        eng.k_cache[li][:, :, :pos, :hd] = torch.roll(kb[rows], sh, dims=2)[:, :, :pos]
+        eng.v_cache[li][:, :, :pos, :hd] = torch.roll(vb[rows], sh, dims=2)[:, :, :pos]
+
+
+def test_config2_bf16_same_batch_alone_and_inside_a_ten_batch_chain():
+    """bf16 results depend on the SCHEDULE, within the oracle's own spread: below 256 rows the decode GEMMs are the K-splitting
+    skinny kernels (8 waves x K/8, partial sums combined in a fixed order), from 256 rows the tile family (one wave accumulates an
+    element over k in order) -- two legitimate fp32 accumulation orders, as different BLAS kernels are for the reference (SURVEY
+    8c).  Here the SAME batch of 32 images is evaluated teacher-forced on identical tokens and cache contents (a) alone -- 64 CFG rows,
+    what `generate()` of one batch runs -- and (b) as batch 3 of a ten-batch chain -- 640 rows, what `bench.py` times: its
+    CFG-mixed logits must agree within the bar every HIP-vs-oracle test uses, max(4 / 0.25 ulp, 2 x the oracle's fp32-vs-fp64
+    self-distance); the measured distance goes to gpurun_out/headline_parity.jsonl (INTEGRATION.md quotes it)."""
+    dev, dt = _dev(), torch.bfloat16
+    m, sd = build_gpt_holder(GPTL_CASE)
+    m = m.to(device=dev, dtype=dt)
+    cfgo = oracle_cfg(GPTL_CASE)
+    n, G, j, N, V, hd = 32, 10, 3, 576, 16384, 64
+    g = torch.Generator().manual_seed(91)
+    cond = torch.randint(0, 1000, (n * G,), generator=g)
+    rows_x = torch.cat([torch.arange(j * n, (j + 1) * n), n * G + torch.arange(j * n, (j + 1) * n)])   # batch j's rows in the chain
+    null = torch.ones_like(cond) * cfgo.num_classes
+    chain_cond, x_cond = torch.cat([cond, null]), torch.cat([cond, null])[rows_x]
+    big, small = m, m.lane_view()
+    big.setup_caches(2 * n * G, 1 + N, dt)
+    small.setup_caches(2 * n, 1 + N, dt)
+    eb, es = big._engine, small._engine
+    assert eb.MTs == 40 and es.MTs == 4
+    fam_b, fam_s = {v["family"] for v in eb.gemm_schedule().values()}, {v["family"] for v in es.gemm_schedule().values()}
+    assert fam_b == {"tile"} and fam_s == {"skinny"}, (fam_b, fam_s)
+    oracles = [O.GPTOracle(cfgo, sd, dt), O.GPTOracle(cfgo, sd, dt)]
+    for o in oracles:
+        o.setup_caches(2 * n, 1 + N)
+    S8 = eb.S8
+    kb = (torch.randn(2 * n * G, cfgo.n_head, S8, hd, generator=g) * 0.6).to(dt).to(dev)
+    vb = (torch.randn(2 * n * G, cfgo.n_head, S8, hd, generator=g) * 0.6).to(dt).to(dev)
+    steps = [("prefill", None, torch.arange(0, 1))]
+    for i in (1, 2):
+        steps.append((f"pos{i}", torch.randint(0, V, (n * G, 1), generator=g), torch.tensor([i])))
+    for p in (299, 574):
+        steps.append((f"late{p}", torch.randint(0, V, (n * G, 1), generator=g), torch.tensor([p])))
+    for label, tok, ipos in steps:
+        if label.startswith("late"):
+            p = int(ipos[0])
+            _rows_fill(eb, kb, vb, torch.arange(2 * n * G, device=dev), p, hd)
+            _rows_fill(es, kb, vb, rows_x.to(dev), p, hd)
+            kx, vx = kb[rows_x.to(dev)].cpu(), vb[rows_x.to(dev)].cpu()
+            for o in oracles:
+                for li in range(len(o.k_cache)):
+                    sh = (li * 37) % S8
+                    o.k_cache[li][:, :, :p] = torch.roll(kx, sh, dims=2)[:, :, :p].float()
+                    o.v_cache[li][:, :, :p] = torch.roll(vx, sh, dims=2)[:, :, :p].float()
+        if tok is None:
+            lb, _ = big(None, chain_cond.to(dev), ipos.to(dev))
+            ls, _ = small(None, x_cond.to(dev), ipos.to(dev))
+            refs = [oracles[0].forward(None, x_cond, ipos)[:, -1]]
+            with _Linear64():
+                refs.append(oracles[1].forward(None, x_cond, ipos)[:, -1])
+        else:
+            t2 = torch.cat([tok, tok])
+            lb, _ = big(t2.to(dev), None, ipos.to(dev).to(torch.int))
+            ls, _ = small(t2[rows_x].to(dev), None, ipos.to(dev).to(torch.int))
+            refs = [oracles[0].forward(t2[rows_x], None, ipos)[:, -1]]
+            with _Linear64():
+                refs.append(oracles[1].forward(t2[rows_x], None, ipos)[:, -1])
+        in_chain = O.cfg_mix(lb[:, -1].float().cpu()[rows_x], 4.0)
+        alone = O.cfg_mix(ls[:, -1].float().cpu(), 4.0)
+        r0, r1 = O.cfg_mix(refs[0], 4.0), O.cfg_mix(refs[1], 4.0)
+        ulp = r0.abs().max().item() * 2.0 ** -8
+        d, s_ = (in_chain - alone).abs(), (r1 - r0).abs()
+        rec = dict(step=label, ulp=ulp, chain_vs_alone_max=d.max().item() / ulp, chain_vs_alone_mean=d.mean().item() / ulp,
+                   self_max=s_.max().item() / ulp, self_mean=s_.mean().item() / ulp,
+                   chain_vs_oracle_max=(in_chain - r0).abs().max().item() / ulp, alone_vs_oracle_max=(alone - r0).abs().max().item() / ulp,
+                   identical_fraction=float((d == 0).float().mean()),
+                   argmax_agree=float((in_chain.argmax(-1) == alone.argmax(-1)).float().mean()))
+        _log("config2_same_batch_alone_vs_chain", rec)
+        assert rec["chain_vs_alone_max"] <= max(4.0, 2.0 * rec["self_max"]), rec
+        assert rec["chain_vs_alone_mean"] <= max(0.25, 2.0 * rec["self_mean"]), rec
+
+
+def test_bf16_free_running_agreement_report():
+    """bf16 free-running token streams cannot be asserted equal against ANY second implementation (the
+    reference's own stream changes with the accumulation order of its BLAS: 0 / 16 sequences), so this test REPORTS instead:
+    GPT-L (24 layers) bf16, 8 images, cfg 4.0, top-k 2000, all 576 tokens from the same Exp(1) draws -- the HIP path (alone: 16 CFG
+    rows on the skinny kernels, AND the same images inside a 640-row tile chain) against the oracle, next to the oracle against its own fp64-
+    accumulating evaluation: per image the first diverging step, per step the fraction of images still on the oracle's stream,
+    and at each first divergence the oracle's margin between its two best candidates (log(p/q) gap: a near-tie is what flips).
+    Written to gpurun_out/r05_bf16_free_running.json (committed as profiles/r05_bf16_free_running.json).  The only assertions:
+    streams are valid, the first token (prefill, one layer stack, no feedback yet) agrees for most images, and the HIP path does
+    not fall off the oracle's stream at once where the oracle's own second evaluation stays on it (median first divergence >=
+    min(8, 1/4 of that evaluation's)) -- loose on purpose: eight geometric-like samples, a report, not a gate."""
+    from llamagen_amd import generate
+    dev, dt = _dev(), torch.bfloat16
+    m, sd = build_gpt_holder(GPTL_CASE)
+    m = m.to(device=dev, dtype=dt)
+    cfgo = oracle_cfg(GPTL_CASE)
+    B, N, V = 8, 576, 16384
+    g = torch.Generator().manual_seed(17)
+    cond = torch.randint(0, 1000, (B,), generator=g)
+    noise = torch.empty(N, B, V).exponential_(1.0, generator=g)
+    kw = dict(cfg_scale=4.0, cfg_interval=-1, temperature=1.0, top_k=2000, top_p=1.0, sample_logits=True)
+    qs = iter(noise)
+    trace = []
+    ref = O.generate(O.GPTOracle(cfgo, sd, dt), cond, N, noise_fn=lambda s: next(qs), trace=trace, **kw)
+    qs = iter(noise)
+    with _Linear64():
+        ref64 = O.generate(O.GPTOracle(cfgo, sd, dt), cond, N, noise_fn=lambda s: next(qs), **kw)
+    hip64 = generate(m, cond.to(dev), N, _noise_seq=noise.to(dev), **kw).cpu()
+    assert m._engine.MTs == 1
+    # the same 8 images as the first 8 of a 320-image chain (640 rows: tile GEMMs + persistent attention); the other images get
+    # their own labels and noise
+    Bc = 320
+    cond_c = torch.cat([cond, torch.randint(0, 1000, (Bc - B,), generator=g)])
+    noise_c = torch.empty(N, Bc, V, device=dev)
+    gd = torch.Generator(device=dev).manual_seed(5)
+    for jn in range(N):
+        noise_c[jn].exponential_(1.0, generator=gd)
+    noise_c[:, :B] = noise.to(dev)
+    view = m.lane_view()
+    hip640 = generate(view, cond_c.to(dev), N, _noise_seq=noise_c, **kw).cpu()[:B]
+    assert view._engine.MTs == 40
+
+    def first_div(a, b):
+        ne = (a != b)
+        return [int(r.float().argmax()) if bool(r.any()) else N for r in ne]
+
+    def survival(fd):
+        return [round(sum(1 for f in fd if f > i) / len(fd), 3) for i in range(0, N, 32)]
+
+    def margins(fd):
+        out = []
+        for b, f in enumerate(fd):
+            if f >= N:
+                continue
+            lg = trace[f][b]
+            lp = torch.log_softmax(O.top_k_top_p_filtering(lg.clone()[None], top_k=2000)[0], -1)
+            r = lp - torch.log(noise[f, b])
+            top2 = torch.topk(r, 2).values
+            out.append(round(float(top2[0] - top2[1]), 5))
+        return out
+
+    rep = {}
+    for name, toks in (("hip_16rows_skinny", hip64), ("hip_640rows_tile", hip640), ("oracle_fp64_accumulation", ref64)):
+        fd = first_div(toks, ref)
+        rep[name] = dict(first_divergence_step=fd, identical_sequences=sum(1 for f in fd if f >= N),
+                         on_oracle_stream_every_32_steps=survival(fd), oracle_top2_log_ratio_gap_at_divergence=margins(fd),
+                         token_agreement_overall=round(float((toks == ref).float().mean()), 4))
+        assert int(toks.min()) >= 0 and int(toks.max()) < V
+    rep["workload"] = "GPT-L 24 layers bf16, 8 images, cfg 4.0, top-k 2000, 576 tokens, same Exp(1) draws; reference = oracle (fp32 accumulation)"
+    rep["hip_16rows_vs_hip_640rows_first_divergence_step"] = first_div(hip64, hip640)
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        json.dump(rep, open(os.path.join(out, "r05_bf16_free_running.json"), "w"), indent=1)
+    med = lambda v: sorted(v)[len(v) // 2]
+    base = med(rep["oracle_fp64_accumulation"]["first_divergence_step"])
+    for name in ("hip_16rows_skinny", "hip_640rows_tile"):
+        fd = rep[name]["first_divergence_step"]
+        assert sum(1 for f in fd if f >= 1) >= B // 2, (name, fd)
+        assert med(fd) >= min(8, base // 4), (name, fd, rep["oracle_fp64_accumulation"]["first_divergence_step"])
 
 
 def _pinned(min_mts):
@@ -302,9 +509,7 @@ def test_fused_norm_gemm_passes_bit_identical(M):
 TILE_NORM = [(4, 1, 1, 3, 4, 4, 4), (4, 1, 1, 6, 4, 3, 4), (4, 1, 2, 8, 2, 4, 4), (4, 1, 1, 4, 4, 4, 4), (4, 1, 1, 6, 2, 4, 4),
              (4, 1, 1, 8, 2, 4, 4), (4, 1, 2, 4, 2, 4, 4), (4, 1, 2, 6, 2, 4, 4), (4, 1, 1, 2, 4, 4, 4), (4, 1, 1, 3, 4, 4, 0),
              (8, 1, 1, 8, 2, 4, 4), (8, 1, 1, 6, 2, 4, 4), (8, 1, 1, 4, 2, 4, 4),
-             (4, 1, 1, 8, 2, 6, 4), (4, 1, 1, 8, 2, 5, 4),
-             (2, 2, 4, 4, 2, 4, 16), (2, 2, 4, 4, 2, 4, 12), (2, 2, 2, 4, 2, 4, 12), (2, 2, 4, 2, 2, 4, 16), (2, 2, 4, 2, 2, 4, 12), (2, 2, 2, 2, 4, 4, 12),
-                    (4, 2, 2, 4, 2, 4, 16), (2, 4, 4, 2, 2, 4, 16)]
+             (4, 1, 1, 8, 2, 6, 4), (4, 1, 1, 8, 2, 5, 4)]
 TILE_PLAIN = [(2, 2, 1, 1, 4, 4, 4), (2, 2, 1, 2, 4, 4, 4), (2, 2, 2, 1, 4, 4, 4), (2, 2, 2, 2, 4, 4, 4), (2, 2, 2, 2, 2, 4, 4),
               (4, 1, 1, 2, 4, 4, 4), (2, 2, 1, 1, 4, 4, 0), (2, 2, 4, 1, 4, 4, 4), (2, 2, 4, 2, 2, 4, 4), (2, 2, 2, 2, 2, 9, 4), (2, 2, 2, 2, 2, 6, 4)]
 
@@ -509,17 +714,19 @@ def test_decode_code_batch32_384px_vs_oracle():
     assert worst < 1e-3, worst  # north_star: decoded pixels within 1e-3 abs
 
 
-def _searched_tile_schedule(e):
-    """A chain of >= 256 rows of a model without a measured table: RMSNorm fused, tile shapes from the on-device search (every
-    GEMM kind got either an instantiated shape or the skinny kernels), the search left the workspaces as it found them."""
-    from llamagen_amd.engine import TILE_SHAPES_NORM, TILE_SHAPES_PLAIN
-    assert e.fuse_norm and e.tile_schedule_source() == "search"
+def _pinned_model_schedule(e):
+    """A chain of >= 256 rows of GPT-XXL / GPT-3B: RMSNorm fused, every decode GEMM on the tile family with the shapes
+    engine.MODEL_TILE_SCHEDULES pins for that model (round 5: no on-device search, no timing-dependent family), and the engine
+    reports the schedule as one an end-to-end test names -- this test."""
+    from llamagen_amd.engine import MODEL_TILE_SCHEDULES, tile_schedule_key
+    assert e.fuse_norm and e.tile_schedule_source() == "table"
+    table = MODEL_TILE_SCHEDULES[(e.d, e.F, e.V)]
+    t = table[tile_schedule_key(e.MTs, table)]
     sched = e.gemm_schedule()
-    fam = {k: v["family"] for k, v in sched.items()}
-    for k, v in sched.items():
-        if v["family"] == "tile":
-            assert tuple(v["shape(wm,wn,mtv,ntv,kb,stages,lw)"]) in (TILE_SHAPES_PLAIN if k in ("wo", "w2") else TILE_SHAPES_NORM), sched
-    assert "tile" in fam.values(), (sched, e.tile_search_report if hasattr(e, "tile_search_report") else None)
+    assert all(v["family"] == "tile" for v in sched.values()), sched
+    want = {"wqkv": t["qkv"], "wo": t["wo"], "w13": t["w13"], "w2": t["w2"], "lm_head": t["head"]}
+    assert want == {k: tuple(v["shape(wm,wn,mtv,ntv,kb,stages,lw)"]) for k, v in sched.items()}, sched
+    assert e.tile_schedule_tested()
     return sched
 
 
@@ -528,7 +735,7 @@ def test_config4_gpt3b_shapes_bf16_vs_oracle(B):
     """BASELINE config 4 kernel shapes: GPT-3B widths (d 3200, 32 heads, head_dim 100 -> padded 128, F 8704),
     B = 64 -> 128 rows (MTs 8), 384 px (S8 584); depth cut to 4 layers so that the oracle finishes in seconds.
     B = 128: the 256-row chain `bench.py --config 4` runs (two batches of 64): RMSNorm fused (200 partial sums per row), the
-    big-M tile family with shapes from the on-device search."""
+    big-M tile family with the pinned GPT-3B shapes (engine.MODEL_TILE_SCHEDULES)."""
     kw = dict(n_layer=4, n_head=32, dim=3200, vocab_size=16384, block_size=576, num_classes=1000, cls_token_num=1,
               model_type="c2i")
     case = dict(kwargs=kw, wseed=22, lin_std=0.02)
@@ -537,7 +744,7 @@ def test_config4_gpt3b_shapes_bf16_vs_oracle(B):
     e = m._engine
     assert e.hd == 100 and e.hdp == 128 and e.MTs == B // 8 and e.F == 8704
     if B == 128:
-        _log("config4_gpt3b_shapes_256rows", dict(schedule=str(_searched_tile_schedule(e))))
+        _log("config4_gpt3b_shapes_256rows", dict(schedule=str(_pinned_model_schedule(e))))
     _check(f"config4_gpt3b_shapes_b{B}", recs)
 
 
@@ -562,18 +769,19 @@ def test_config5_gptxl_t2i_shapes_bf16_vs_oracle():
     _check("config5_gptxl_t2i_shapes", recs)
 
 
-@pytest.mark.parametrize("B", [32, 128])
+@pytest.mark.parametrize("B", [32, 128, 192])
 def test_config3_gptxxl_shapes_bf16_vs_oracle(B):
     """BASELINE config 3 per-GPU kernel shapes: GPT-XXL widths (d 1536, 24 heads, F 4096; fused-norm CPW 6), B = 32 -> 64
-    rows, 384 px; depth cut to 4 layers."""
+    rows, 384 px; depth cut to 4 layers.  B = 128 / 192: chains of 256 / 384 rows (`bench.py --config 3` runs two chains of six
+    batches = 384 rows) on the pinned GPT-XXL tile shapes."""
     kw = dict(n_layer=4, n_head=24, dim=1536, vocab_size=16384, block_size=576, num_classes=1000, cls_token_num=1,
               model_type="c2i")
     case = dict(kwargs=kw, wseed=24, lin_std=0.02)
     cond = torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(6))
     recs, m = _teacher_forced(case, B, 4.0, early=3, late=[575], cond=cond)
     assert m._engine.fuse_norm
-    if B == 128:   # the 256-row chain `bench.py --config 3` runs (four batches of 32): tile family, searched shapes
-        _log("config3_gptxxl_shapes_256rows", dict(schedule=str(_searched_tile_schedule(m._engine))))
+    if B >= 128:   # tile family, pinned shapes
+        _log(f"config3_gptxxl_shapes_{2 * B}rows", dict(schedule=str(_pinned_model_schedule(m._engine))))
     _check(f"config3_gptxxl_shapes_b{B}", recs)
 
 

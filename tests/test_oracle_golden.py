@@ -207,7 +207,14 @@ def test_oracle_full_depth_configs_3_4_5_vs_reference(name):
     check_full_depth(case, dist)
 
 
+FULL_DEPTH_CEILING = (20.0, 3.5)   # bf16 ulps of the largest logit (max, mean): whatever the oracle's own distance, nothing passes above this
+
+
 def check_full_depth(case, dist):
+    """Bar per step: max(8 / 1.3 ulp, 2 x the oracle-vs-reference distance measured when the goldens were made) -- tests/cases.py --
+    AND a fixed ceiling, so that a regression cannot hide behind a loose oracle (GPT-XXL's late step: the oracle itself is 15.8 /
+    2.6 ulp from the reference, 2 x that would admit 31.6; measured HIP distances are 4.5-12.7 / 0.8-2.5)."""
     for label, (emax, emean) in dist.items():
         bmax, bmean = case["bar_late"] if label.startswith("late") else case["bar_early"]
+        bmax, bmean = min(bmax, FULL_DEPTH_CEILING[0]), min(bmean, FULL_DEPTH_CEILING[1])
         assert emax <= bmax and emean <= bmean, (label, emax, emean, bmax, bmean)

@@ -65,6 +65,32 @@ def timed(pairs):
     return best
 
 
+def timed_under(fg, bg, t_fg, t_bg):
+    """us per replay of graph `fg` (events on its stream around REPS replays) while `bg` replays back to back on the other stream
+    for at least twice as long: how far a chain's kernels stretch beside the other chain's."""
+    (g1, s1), (g2, s2) = fg, bg
+    nbg = max(REPS, int(3.0 * REPS * max(t_fg, 1.0) / max(t_bg, 1.0)) + REPS)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(s2):
+        for _ in range(REPS // 2):
+            g2.replay()
+    with torch.cuda.stream(s1):
+        e0.record()
+    k = 0
+    for i in range(REPS):
+        with torch.cuda.stream(s1):
+            g1.replay()
+        while k < (i + 1) * nbg // REPS:
+            with torch.cuda.stream(s2):
+                g2.replay()
+            k += 1
+    with torch.cuda.stream(s1):
+        e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / REPS
+
+
 def main():
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
@@ -102,6 +128,11 @@ def main():
         t = timed(pairs)
         print(f"  {name}: {t:8.1f} us   sum {sum(parts):8.1f}  max {max(parts):8.1f}  -> overlap {(sum(parts) - t) / min(parts):5.2f} "
               f"(1 = the shorter one fully hidden)", flush=True)
+    tGA, tAG = timed_under((G2, s2), (A1, s1), tG, tA), timed_under((A1, s1), (G2, s2), tA, tG)
+    print(f"  G under A: {tGA:8.1f} us per GEMM graph ({tGA / tG:4.2f} x alone)   A under G: {tAG:8.1f} us per attention graph ({tAG / tA:4.2f} x alone)",
+          flush=True)
+    if os.environ.get("NO_V") == "1":
+        return
     # decoder beside a chain: REPS x A (or G) on s1 while one decode_code() of 32 images runs on s2
     torch.cuda.synchronize()
     t0 = time.perf_counter()

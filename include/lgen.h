@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LGEN_ABI_VERSION 7
+#define LGEN_ABI_VERSION 8
 #define LGEN_BF16 0
 #define LGEN_F32 1
 #define LGEN_F16 2   /* fp16 storage: BF16's layouts (KC = 32, EPL = 8), IEEE half rounding, v_mfma_f32_16x16x32_f16 */
@@ -236,6 +236,17 @@ int lgen_conv_fused_bn(int Cout);
 int lgen_conv_fused(const float* x_nhwc, const float* gn_coef, int swish, const void* w_frag, const float* bias,
                     const float* res, float* out, float* stats_partial, int B, int H, int W, int Cin, int Cout, int Npad,
                     int ksize, int upsample, int out_nchw, void* stream);
+
+/* The same operation for 3x3 convolutions in Winograd F(2x2, 3x3) form (round 5, ABI v8; csrc/conv_wino.hip): 16 instead of 36
+ * MFMA products per 2 x 2 output block and input channel, transforms in fp32, products in the same 3-pass split-bf16 form on the
+ * transformed operands.  Same argument meaning as lgen_conv_fused (x read once as fp32 NHWC [B][H>>upsample][W>>upsample][Cin],
+ * gn_coef / swish applied on the tile load, bias, res, NHWC out, stats_partial [B][(H/8)*(W/16)][Cout/4][2]) for the shapes the
+ * form covers: H % 8 == 0, W % 16 == 0, Cin % 32 == 0, Cout % 128 == 0; LGEN_ERR_UNSUPPORTED otherwise (use lgen_conv_fused).
+ * u_frag: the transformed weights U = G g G^T (g = weight[cout][cin] 3x3, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]), (hi, lo)
+ * bf16 split, in MFMA fragment order [Cout/128][Cin/32][16 positions pi*4+pj][2 planes][8 cout tiles][64 lanes][8]. */
+int lgen_conv_wino(const float* x_nhwc, const float* gn_coef, int swish, const void* u_frag, const float* bias,
+                   const float* res, float* out, float* stats_partial, int B, int H, int W, int Cin, int Cout,
+                   int upsample, void* stream);
 
 /* GroupNorm(32, C, eps) statistics -> per-channel (scale, shift) = (rstd*gamma, beta - rstd*gamma*mean), coef [B][C][2].
  * Source: partial != NULL: the tile partials of lgen_conv_fused ([B][ntiles][quad_stride][2] = (sum, M2 about the partial's

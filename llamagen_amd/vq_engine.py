@@ -81,7 +81,7 @@ class VQEngine:
             self.lib.lgen_debug_set_vq_nt(int(os.environ["LGEN_VQ_NT"]))
         self.dev = model.post_quant_conv.weight.device
         self.fused = os.environ.get("LGEN_VQ_FUSED", "1") != "0"  # lgen_conv_fused where the shape allows it
-        self.wino = os.environ.get("LGEN_VQ_WINO", "1") != "0"    # lgen_conv_wino (Winograd F(2x2, 3x3)) for the 3x3 convs it covers
+        self.wino = os.environ.get("LGEN_VQ_WINO", "0") == "1"    # lgen_conv_wino (Winograd F(2x2, 3x3)): opt-in until it beats the direct form
         if os.environ.get("LGEN_CF_VARIANT") is not None:  # tuning knob, see lgen_debug_set_conv_fused_variant in lgen.h
             self.lib.lgen_debug_set_conv_fused_variant(int(os.environ["LGEN_CF_VARIANT"]))
         cfg = model.config

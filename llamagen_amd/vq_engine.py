@@ -54,8 +54,12 @@ class _ConvW:
             U = (G @ w.double() @ G.t()).float()                                   # [cout][cin][4][4]
             ut = U.permute(2, 3, 0, 1).reshape(16, cout, cin).contiguous()
             uh, ul = _split_planes(ut)
-            pkw = lambda q: q.view(16, cout // 128, 8, 16, cin // 32, 4, 8).permute(1, 4, 0, 2, 5, 3, 6)
-            self.wino = torch.stack([pkw(uh), pkw(ul)], dim=3).contiguous()        # [nb][kc][position][plane][j][g][r][8]
+            # kernel order (csrc/conv_wino.hip): [nb][kc][sub-step ss = pj * 4 + jt][wave = pi * 2 + wn][hi|lo][g][r][8], where the
+            # fragment is position pi * 4 + pj, cout tile wn * 4 + jt of the 128-channel block -- the (hi, lo) pair one wave needs in
+            # one sub-step is contiguous (its private DMA)
+            up = torch.stack([uh, ul])                                              # [plane][position][cout][cin]
+            up = up.view(2, 4, 4, cout // 128, 2, 4, 16, cin // 32, 4, 8)           # plane, pi, pj, nb, wn, jt, r, kc, g, e
+            self.wino = up.permute(3, 7, 2, 5, 1, 4, 0, 8, 6, 9).contiguous()       # nb, kc, pj, jt, pi, wn, plane, g, r, e
 
 
 class _GNW:

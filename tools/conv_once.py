@@ -33,5 +33,11 @@ def run():
 run(); torch.cuda.synchronize(); t = time.time()
 for _ in range(reps): run()
 torch.cuda.synchronize(); dt = (time.time() - t) / reps
+if variant == 2 and int(os.environ.get("LGEN_WINO_ABLATE", "0")) & 32:
+    tm = part.reshape(-1)[:64].cpu().view(8, 8)
+    names = ["barrier a", "halo issue + transform", "barrier b", "sub-steps 0-2 (+3's wait)", "store_halo", "sub-steps 3-15", "epilogue", "loop top"]
+    tot = tm[0].sum().item()
+    print("wave 0 of workgroup 0, shader clocks per phase (share):", ", ".join(f"{n} {tm[0, k].item() / tot:.3f}" for k, n in enumerate(names)), f"total {tot:.3e}")
+    print("per wave totals:", [f"{tm[w].sum().item():.3e}" for w in range(8)])
 fl = 3 * 2 * 9 * Cin * Cout * H * H * B
 print(f"{'conv_wino' if variant == 2 else 'conv_fused'} v{variant} wino_ablate={os.environ.get('LGEN_WINO_ABLATE', 0)} abl={abl} B={B} {H}x{H} {Cin}->{Cout}: {dt*1e3:.3f} ms  {fl/dt/1e12:.0f} TFLOP/s (3-pass)")

@@ -115,6 +115,8 @@ struct QkvCol {
 // ring stages): every touch pulls its line through the CU's vector L1, the same path the DMA pieces take, so the feed traffic
 // doubles -- wo 6.7 -> 9.8 us, w2 10.5 -> 15.6, w1||w3 17.9 -> 23.2, bench 112 against 122 img/s.  What that says: these kernels
 // are bound by the L2 -> CU feed (~45 B/clk/CU by LDS-DMA), i.e. by tile perimeter x K bytes per CU, not by LDS reads or MFMA.
+// (c) deeper rings -- 5 / 6 stages for wqkv, 6 / 9 half-size stages for wo / w2: the same alone, 122.3-122.9 against 121.6-123.4 img/s
+// in the bench over two boxes (r05_first_ab.log, r05_ab3.log): inside the box spread, instantiations removed again.
 template <typename D, int WM, int WN, int MTV, int NTV, int KB, int STAGES, int EPI, bool NORM, int LW>
 __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_tile_kernel(GemmArgs a) {
     constexpr int NC = WM * WN, NL = LW ? LW : NC, MTW = WM * MTV, NTW = WN * NTV;
@@ -515,13 +517,10 @@ static int gt_launch(const GemmArgs& a_in, hipStream_t st) {
 #define GT_SHAPES_NORM(X)                                                                                        \
     X(4, 1, 1, 3, 4, 4, 4) X(4, 1, 1, 4, 4, 4, 4) X(4, 1, 1, 6, 2, 4, 4) X(4, 1, 1, 6, 4, 3, 4) X(4, 1, 1, 8, 2, 4, 4) \
     X(4, 1, 2, 4, 2, 4, 4) X(4, 1, 2, 6, 2, 4, 4) X(4, 1, 2, 8, 2, 4, 4) X(4, 1, 1, 2, 4, 4, 4) X(4, 1, 1, 3, 4, 4, 0) \
-    X(8, 1, 1, 8, 2, 4, 4) X(8, 1, 1, 6, 2, 4, 4) X(8, 1, 1, 4, 2, 4, 4)                                          \
-    /* deeper rings (round 5: more operand bytes in flight per CU for the contended regime; 122.9 against 121.6 img/s in one bench A/B) */ \
-    X(4, 1, 1, 8, 2, 6, 4) X(4, 1, 1, 8, 2, 5, 4)
+    X(8, 1, 1, 8, 2, 4, 4) X(8, 1, 1, 6, 2, 4, 4) X(8, 1, 1, 4, 2, 4, 4)
 #define GT_SHAPES_PLAIN(X)                                                                                       \
     X(2, 2, 1, 1, 4, 4, 4) X(2, 2, 1, 2, 4, 4, 4) X(2, 2, 2, 1, 4, 4, 4) X(2, 2, 2, 2, 4, 4, 4) X(2, 2, 2, 2, 2, 4, 4) \
-    X(4, 1, 1, 2, 4, 4, 4) X(2, 2, 1, 1, 4, 4, 0) X(2, 2, 4, 1, 4, 4, 4) X(2, 2, 4, 2, 2, 4, 4)                   \
-    X(2, 2, 2, 2, 2, 9, 4) X(2, 2, 2, 2, 2, 6, 4)
+    X(4, 1, 1, 2, 4, 4, 4) X(2, 2, 1, 1, 4, 4, 0) X(2, 2, 4, 1, 4, 4, 4) X(2, 2, 4, 2, 2, 4, 4)
 
 template <typename D, int EPI, bool NORM>
 static int gt_dispatch(const GemmArgs& a, int wm, int wn, int mtv, int ntv, int kb, int stages, int lw, hipStream_t st) {

@@ -79,8 +79,8 @@ def plan_schedule(args, B, N, T):
         bpc = {4: 2, 5: 4}[args.config]   # GPT-3B: 4 batches x 1 chain measured 25.2 img/s against 28.2 for 2 x 2
     chains = (args.steps + bpc - 1) // bpc
     n_layer, n_head, dim = GPT_DIMS[CONFIGS[args.config]["gpt"]]
-    hdp = 64 if dim // n_head <= 64 else 128
-    per_chain = (n_layer * 2 * B * bpc * n_head * (T + N + 8) * hdp * 2 * 2      # K and V slabs, CFG rows
+    kvs = -(-(dim // n_head) // 8) * 8   # elements between key rows: head_dim rounded up to one 16-byte piece (engine.py)
+    per_chain = (n_layer * 2 * B * bpc * n_head * (T + N + 8) * kvs * 2 * 2      # K and V slabs, CFG rows
                  + N * B * bpc * 16384 * 4)                                       # Exp(1) noise
     if args.lanes <= 0:
         if args.config in (2, 3):
@@ -809,7 +809,7 @@ def main():
 
 HBM_BUDGET_BYTES = 180e9   # KV slabs + noise of the chains in flight per GPU (288 GB HBM3E minus weights, decoder activations, slack)
 MFMA_BF16_PEAK_TFLOPS = 2500.0
-PMC_JSON = "r04_pmc.json"
+PMC_JSON = "r05_pmc.json"
 
 
 def PMC_POSITIONS(N, T=1):

@@ -84,8 +84,12 @@ int lgen_gemm_max_kw(int epilogue_kind, int fused_norm, int mt, int nt);
 
 /* Attention.forward front half (gpt.py:214-226): [attention_norm, gpt.py:254 +] wqkv GEMM +
  * apply_rotary_emb(q,k) (gpt.py:420-430) + KVCache.update at *pos_ptr (gpt.py:177-185).
- * q_out [MTs*16][H][hdp]; caches [B2][H][S8] rows of hdp elements, kv_row_stride elements apart (0 = hdp;
- * 2*hdp with v_cache = k_cache + hdp is the interleaved K|V slab the engine uses: one HBM stream per (b, h));
+ * q_out [MTs*16][H][hdp]; caches [B2][H][S8] rows of hd valid elements, kv_row_stride elements apart (0 = hdp;
+ * 2*hdp with v_cache = k_cache + hdp is an interleaved K|V slab: one HBM stream per (b, h)).  Round 5: kv_row_stride may be
+ * SMALLER than the lane group hdp, down to hd rounded up to 8 elements (GPT-3B: hd 100 -> rows 104 elements = 13 x 16 B apart
+ * instead of 128): the attention kernels still read hdp elements per key -- the lanes past the row read the first bytes of the
+ * NEXT row, which multiply q's zero pad lanes (QK^T) or land in output elements >= hd that are never stored (PV) -- so every
+ * cache must be followed by >= (hdp - kv_row_stride) readable, finite elements (the engine allocates that slack);
  * freqs [P][hd/2][2] fp32 from precompute_freqs_cis_2d (gpt.py:404-417); norm_w / ssq_in / ssq_parts / eps as
  * in lgen_gemm; passes as in lgen_gemm. */
 int lgen_gemm_qkv_rope(const void* wp, const void* xp, void* q_out, void* k_cache, void* v_cache, const float* freqs,

@@ -533,7 +533,7 @@ static int attn_decode_impl(const void* q, const void* k_cache, const void* v_ca
     hipStream_t st = (hipStream_t)stream;
     const int epl = dtype != LGEN_F32 ? 8 : 4;
     if (dtype != LGEN_BF16 && dtype != LGEN_F32 && dtype != LGEN_F16) return LGEN_ERR_BAD_ARG;
-    if (hdp % epl || hd > hdp || B2 > MTs * 16 || S8 < 1 || a.kvs < hdp || a.kvs % epl) return LGEN_ERR_BAD_ARG;
+    if (hdp % epl || hd > hdp || B2 > MTs * 16 || S8 < 1 || a.kvs < (hd + epl - 1) / epl * epl || a.kvs % epl) return LGEN_ERR_BAD_ARG;
     const int lpk = hdp / epl;
     // default variant 2; chains of >= 256 rows put two heads of a row into a workgroup (variant 6: 49.8 vs 50.7 us average launch
     // at 256 rows, 27.3 vs 27.0 at 128: tools/attn_sweep.py, profiles/r03_attn_sweep.log)

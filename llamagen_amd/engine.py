@@ -213,9 +213,17 @@ class DecodeEngine:
             self.k_cache, self.v_cache = self.kv_slab[..., 0, :], self.kv_slab[..., 1, :]
             self.kvs = 2 * self.hdp
         else:
-            self.k_cache = z(self.L, max_batch, self.H, S8, self.hdp)
-            self.v_cache = z(self.L, max_batch, self.H, S8, self.hdp)
-            self.kvs = self.hdp
+            # Rows are packed at hd rounded up to 8 elements (one 16-byte piece), not at the lane group hdp (round 5): GPT-3B's
+            # head_dim 100 -> 104 elements = 13 x 16 B per key instead of 128, i.e. 19 % fewer KV bytes for the HBM-bound decode
+            # attention (the reference's own serving fork pads to 112, autoregressive/serve/gpt_model.py:208-220).  The kernels
+            # still read hdp elements per key: the lanes past the row see the first bytes of the NEXT row, which meet q's zero
+            # pad lanes (QK^T) or output elements >= hd that are never stored (PV); the slack behind the last row keeps those
+            # reads inside the allocation (zeros: finite).  LGEN_KV_PACK=0 keeps rows of hdp elements.
+            self.kvs = _ceil_div(self.hd, self.epl) * self.epl if os.environ.get("LGEN_KV_PACK", "1") != "0" else self.hdp
+            n = self.L * max_batch * self.H * S8 * self.kvs
+            self._k_flat, self._v_flat = z(n + self.hdp), z(n + self.hdp)
+            self.k_cache = self._k_flat[:n].view(self.L, max_batch, self.H, S8, self.kvs)
+            self.v_cache = self._v_flat[:n].view(self.L, max_batch, self.H, S8, self.kvs)
         self.causal_mask = torch.tril(torch.ones(S8, S8, dtype=torch.bool, device=dev)).unsqueeze(0).repeat(max_batch, 1, 1)
         grid = int(cfg.block_size ** 0.5)
         self.freqs_cis = precompute_freqs_cis_2d(grid, self.hd, cfg.rope_base, self.T).to(dev).contiguous()

@@ -255,7 +255,7 @@ def test_fused_rmsnorm_chain(dt, M, d, F, tiles):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("interleave", [False, True])
+@pytest.mark.parametrize("interleave", [False, True, "packed"])   # "packed" (round 5): rows hd rounded up to one 16-byte piece apart (< hdp for head_dim 100), the engine's layout
 @pytest.mark.parametrize("B2,H,hd,grid,pos", [(2, 4, 64, 4, 0), (2, 4, 64, 4, 7), (33, 16, 64, 24, 300), (3, 8, 100, 4, 16),
                                                (192, 16, 64, 8, 40)])   # 3072 (row, head) items: persistent waves walk 1 or 2 items
 def test_qkv_rope_append_and_attention(dt, B2, H, hd, grid, pos, interleave):
@@ -273,7 +273,13 @@ def test_qkv_rope_append_and_attention(dt, B2, H, hd, grid, pos, interleave):
     vcache = _rand((B2, H, S8, hd), dt, 12)
     mts = (B2 + 15) // 16
     mts = {3: 4}.get(mts, mts)
-    if interleave:  # the engine's layout: K and V row of a slot adjacent, row stride 2 * hdp
+    if interleave == "packed":   # rows packed at hd rounded up to 8 (4 for fp32) elements; hdp elements of readable slack behind the last row
+        epl = 4 if dt == torch.float32 else 8
+        KVS = (hd + epl - 1) // epl * epl
+        n = B2 * H * S8 * KVS
+        kflat, vflat = torch.zeros(n + hdp, dtype=dt, device=dev), torch.zeros(n + hdp, dtype=dt, device=dev)
+        kc_d, vc_d = kflat[:n].view(B2, H, S8, KVS), vflat[:n].view(B2, H, S8, KVS)
+    elif interleave:  # K and V row of a slot adjacent, row stride 2 * hdp
         slab = torch.zeros(B2, H, S8, 2, hdp, dtype=dt, device=dev)
         kc_d, vc_d, KVS = slab[..., 0, :], slab[..., 1, :], 2 * hdp
     else:

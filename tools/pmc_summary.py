@@ -1,12 +1,13 @@
 """rocprofv3 counter_collection.csv (FETCH_SIZE pass, WRITE_SIZE pass of tools/pmc_target.py) -> profiles/<TAG>_pmc.json and a
-readable profiles/<TAG>_pmc.csv (TAG = LGEN_PMC_TAG, default r04).  FETCH_SIZE is in KB and counts HALF of a wide coalesced read stream on gfx950
+readable profiles/<TAG>_pmc.csv (TAG = LGEN_PMC_TAG, default r05).  FETCH_SIZE is in KB and counts HALF of a wide coalesced read stream on gfx950
 (MI355X_MICROARCH.md, HBM section): bytes = KB * 1024 * 2; WRITE_SIZE: bytes = KB * 1024."""
 import csv, glob, json, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 d, H, hd, F, V = 1024, 16, 64, 2816, 16384
 B2 = 2 * int(os.environ.get("LGEN_PMC_B", "320"))  # rows of the decode chain (tools/pmc_target.py)
-TAG = os.environ.get("LGEN_PMC_TAG", "r04")
+TAG = os.environ.get("LGEN_PMC_TAG", "r05")
+POS = (50, 300, 575)   # tools/pmc_target.py
 XROW = B2 * d * 2   # bytes of one [rows, d] bf16 panel: the activation operand of a GEMM (and the residual a RES epilogue reads)
 GEMM = {  # kernel-name fragment -> (bench key, algorithmic weight bytes)
     "EPI_QKV": ("wqkv", 3 * d * d * 2), "5, 4>(GemmArgs)": ("wqkv", 3 * d * d * 2),
@@ -75,20 +76,20 @@ def main(fetch_dir, write_dir):
                 res["gemm"][key]["fetch_bytes_per_launch"] = int(tot / n)
             else:
                 res["gemm"].setdefault(key, {})["write_bytes_per_launch"] = int(tot / n)
-        # attention: the LAST 72 attention dispatches are the 3 x 24 full-size launches at positions 63 / 287 / 575
+        # attention: the LAST 72 attention dispatches are the 3 x 24 full-size launches at positions POS
         attn_seq.sort()
         last = [v for _, v in attn_seq[-72:]]
         if len(last) == 72:
             ratios = []
-            for i, pos in enumerate((63, 287, 575)):
+            for i, pos in enumerate(POS):
                 avg = sum(last[i * 24:(i + 1) * 24]) / 24
                 alg = (pos + 1) * 2 * H * hd * 2 * B2
                 table.append((counter, f"attn pos {pos}", 24, avg, alg, avg / alg if counter == "FETCH_SIZE" else avg / (B2 * d * 2)))
                 ratios.append(avg / alg)
             if counter == "FETCH_SIZE":
                 # weight the three positions like a generate() does (bytes grow linearly with position)
-                res["attn_decode_kernel"] = {"fetch_over_algorithmic": round(sum(r * (p + 1) for r, p in zip(ratios, (63, 287, 575))) / 928, 4),
-                                             "fetch_over_algorithmic_by_position": {str(p): round(r, 4) for p, r in zip((63, 287, 575), ratios)}}
+                res["attn_decode_kernel"] = {"fetch_over_algorithmic": round(sum(r * (p + 1) for r, p in zip(ratios, POS)) / sum(p + 1 for p in POS), 4),
+                                             "fetch_over_algorithmic_by_position": {str(p): round(r, 4) for p, r in zip(POS, ratios)}}
             else:
                 res.setdefault("attn_decode_kernel", {})["write_bytes_per_launch"] = int(sum(last) / 72)
     res.setdefault("attn_decode_kernel", {})["source"] = res["gemm"]["source"]

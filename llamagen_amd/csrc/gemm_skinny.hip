@@ -367,7 +367,10 @@ static int qkv_rope_impl(const void* wp, const void* xp, void* q_out, void* k_ca
     a.N = 3 * d; a.KCH = d / kcsz; a.MTs = MTs; a.M = M;
     a.d = d; a.hd = hd; a.hdp = hdp; a.H = n_head; a.S8 = S8;
     a.kvs = kv_row_stride > 0 ? kv_row_stride : hdp;
-    if (a.kvs < ((hd + 7) & ~7) || a.kvs % 8) return LGEN_ERR_BAD_ARG;   // (rows may be packed tighter than the lane group hdp: lgen.h)
+    {   // rows may be packed tighter than the lane group hdp (lgen.h): at least hd rounded up to one 16-byte piece of the storage type
+        const int epl_ = kcsz / 4;
+        if (a.kvs < (hd + epl_ - 1) / epl_ * epl_ || a.kvs % epl_) return LGEN_ERR_BAD_ARG;
+    }
     a.nw = (const uint4*)norm_w; a.ssq_in = ssq_in; a.parts = ssq_parts; a.eps = eps; a.inv_k = 1.0f / (float)d;
     a.passes = passes;
     return dispatch_norm<EPI_QKV>(a, dtype, mt, nt, kw, (hipStream_t)stream);

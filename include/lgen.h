@@ -10,8 +10,10 @@
  * inside the library: (1) one-shot `hipFuncSetAttribute` flags for the kernels that need more than 64 KiB of LDS (set on first use
  * for the current device) and the cached CU count of the persistent attention form; (2) the development switches of the
  * `lgen_debug_*` section at the end of this header (process-wide ints read at launch time, never set by the product path) and the
- * LGEN_GEMM_STEADY / LGEN_TILE_ABLATE environment variables (read at launch = capture time; bit-identical results / timing
- * ablations).  Each entry point cites the reference op sequence it replaces (paths relative to the reference repository root).
+ * LGEN_GEMM_STEADY / LGEN_TILE_ABLATE / LGEN_WINO_ABLATE / LGEN_ATTN_CLAMP environment variables (read at launch = capture time;
+ * bit-identical results / timing ablations / the pre-round-5 key loads of the decode attention for A/B runs).  ABI v8 = v7 +
+ * lgen_conv_wino, and a K/V row stride that may be smaller than the lane group hdp (lgen_gemm_qkv_rope).  Each entry point cites the
+ * reference op sequence it replaces (paths relative to the reference repository root).
  *
  * Fragment-packed layouts ("chunk" = 1 KiB = [16 rows][KC k] in MFMA operand order, lane =
  * g*16 + r holds row r, k-slice g*EPL..+EPL; bf16: KC=32, EPL=8; fp32: KC=16, EPL=4):

@@ -160,6 +160,65 @@ def test_measured_tile_tables_of_round_3(lib):
     assert tiles(1024, 2816, 8, True)["w2"] != (2, 2, 4)                  # 128 rows keep the round-2 shapes
 
 
+def test_pinned_tile_schedules_are_shapes_the_library_takes(lib):
+    """Round 5: engine.MODEL_TILE_SCHEDULES replaces the on-device search.  Every shape of every table must be one the library
+    instantiates for that GEMM at the chain widths the key serves (argument validation runs before the launch: without a GPU the
+    launch then fails with a hip error, which is fine here -- LGEN_ERR_UNSUPPORTED / BAD_ARG is not), the engine must pick the
+    model's own table, and tile_schedule_tested() must say "tested" exactly for the keys an end-to-end test names."""
+    import types
+    from llamagen_amd import _lib as L
+    from llamagen_amd.engine import (DecodeEngine, MODEL_TILE_SCHEDULES, TESTED_MODEL_SCHEDULES, TILE_SCHEDULES, TILE_SCHEDULE_EXACT,
+                                     tile_schedule_key)
+    heads = {1024: 16, 1536: 24, 3200: 32}
+    bad = []
+    for (d, F, V), table in MODEL_TILE_SCHEDULES.items():
+        H, hd = heads[d], d // heads[d]
+        hdp = 64 if hd <= 64 else 128
+        for key, shapes in table.items():
+            widths = [key] if (table is TILE_SCHEDULES and key in TILE_SCHEDULE_EXACT) else [key, key + 8]
+            for mts in widths:
+                if tile_schedule_key(mts, table) != key:
+                    continue
+                M = mts * 16
+                for kind, s in shapes.items():
+                    if kind == "qkv":
+                        rc = lib.lgen_gemm_qkv_rope_tile(8, 8, 8, 8, 8, 8, 8, M, mts, d, H, hd, hdp, 584, (hd + 7) // 8 * 8, L.BF16, *s, 8, 8,
+                                                         d // 16, 1e-5, 0)
+                    else:
+                        N, K, epi, nw = {"wo": (d, d, L.EPI_RES, 0), "w13": (2 * F, d, L.EPI_SWIGLU, 8), "w2": (d, F, L.EPI_RES, 0),
+                                         "head": (V, d, L.EPI_ROWS, 8)}[kind]
+                        rc = lib.lgen_gemm_tile(8, 8, 8, M, mts, N, K, epi, L.BF16, *s, nw, 8 if nw else 0, d // 16, 1e-5, 0 if nw else 8, 0)
+                    if rc in (-1, -2):
+                        bad.append(((d, F, V), key, mts, kind, s, rc))
+    assert not bad, bad
+
+    def eng(d, F, V, mts, **kw):
+        e = types.SimpleNamespace(d=d, F=F, V=V, MTs=mts, hd=64, dtype=torch.bfloat16, fuse_norm=True, use_tile=True, tile_autotune=False,
+                                  tile_shape_override={}, tile_override={}, pass_override={}, pos_rows=None, mt=4, kc=32, lib=lib)
+        e.__dict__.update(kw)
+        for name in ("_tile_shape", "_tiles", "_passes", "gemm_schedule", "tile_schedule_source", "tile_schedule_tested"):
+            setattr(e, name, types.MethodType(getattr(DecodeEngine, name), e))
+        return e
+    gl = eng(1024, 2816, 16384, 40)
+    assert gl._tile_shape("w13") == TILE_SCHEDULES[40]["w13"] and gl.tile_schedule_source() == "table" and gl.tile_schedule_tested()
+    assert not eng(1024, 2816, 16384, 32).tile_schedule_tested()                    # 512 rows: measured, but no end-to-end oracle test
+    assert eng(1024, 2816, 16384, 24).tile_schedule_tested()                        # 384 rows: the 256-row table
+    assert eng(1024, 2816, 16384, 4).tile_schedule_tested()                         # 64 rows: skinny kernels
+    xxl = eng(1536, 4096, 16384, 24)
+    assert xxl._tile_shape("w2") == MODEL_TILE_SCHEDULES[(1536, 4096, 16384)][16]["w2"] and xxl.tile_schedule_tested()
+    b3 = eng(3200, 8704, 16384, 16)
+    assert b3._tile_shape("qkv") == (8, 1, 1, 6, 2, 4, 4) and b3.tile_schedule_tested()
+    other = eng(1280, 3584, 16384, 16)                                              # GPT-XL: no table of its own -> GPT-L's shapes by width
+    assert other._tile_shape("wo") == TILE_SCHEDULES[16]["wo"] and not other.tile_schedule_tested()
+    assert other.tile_schedule_source().startswith("table (GPT-L")
+    assert not eng(1024, 2816, 16384, 40, tile_shape_override={"wo": (2, 2, 1, 1, 4, 4, 4)}).tile_schedule_tested()
+    assert set(TESTED_MODEL_SCHEDULES) == set(MODEL_TILE_SCHEDULES)
+    # K/V rows packed tighter than the lane group (round 5): head_dim 100 takes rows of 104 elements (bf16) / 100 (fp32), not 96
+    for dtype, stride, want_ok in ((L.BF16, 104, True), (L.BF16, 96, False), (L.BF16, 100, False), (L.F32, 100, True), (L.BF16, 128, True)):
+        rc = lib.lgen_gemm_qkv_rope(8, 8, 8, 8, 8, 8, 8, 64, 4, 3200, 32, 100, 128, 584, stride, dtype, 4, 1, 4, 0, 0, 0, 0.0, 1, 0)
+        assert (rc not in (-1, -2)) == want_ok, (dtype, stride, rc)
+
+
 def test_hot_kernels_have_no_register_spills():
     """The build leaves the compiler's per-kernel resource report next to every object
     (llamagen_amd/csrc/*.usage, -Rpass-analysis=kernel-resource-usage).  Every kernel of the library must be free

@@ -105,3 +105,22 @@ def test_bench_standin_single_rank():
     assert r.returncode == 0, r.stderr[-2000:]
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert j["n_gpus"] == 1 and j["rccl_ranks"] == 1
+
+
+def test_config2_schedules_only_tested_chain_widths():
+    """`bench.py` (config 2) only plans chain widths an end-to-end oracle test names -- 1..6 batches per chain (skinny kernels below
+    256 rows, TILE_SCHEDULES[16] from there) or 10 (640 rows, TILE_SCHEDULES[40]) -- whatever --steps says; a wish of 7..9 falls
+    back to 6 (round 4 planned up to 12 and refused the run AFTER the timed region)."""
+    import argparse
+    import bench
+    got = {}
+    for steps in (1, 2, 5, 8, 12, 14, 16, 18, 20, 24, 40):
+        a = argparse.Namespace(config=2, steps=steps, batches_per_chain=0, lanes=0, no_one_chain=True)
+        bpc, per_chain = bench.plan_schedule(a, 32, 576, 1)
+        got[steps] = (bpc, a.lanes)
+        assert bpc in (1, 2, 3, 4, 5, 6, 10) and per_chain > 0
+    assert got[20] == (10, 2) and got[24] == (10, 2) and got[14] == (6, 2) and got[16] == (6, 2) and got[12] == (6, 2) and got[1] == (1, 1)
+    # KV budget: GPT-3B's rows are 104 elements apart, not 128 (config 4)
+    a = argparse.Namespace(config=4, steps=8, batches_per_chain=0, lanes=0, no_one_chain=True)
+    bpc, per_chain = bench.plan_schedule(a, 64, 576, 1)
+    assert bpc == 2 and abs(per_chain - (24 * 2 * 64 * 2 * 32 * 585 * 104 * 2 * 2 + 576 * 64 * 2 * 16384 * 4)) < 1e6

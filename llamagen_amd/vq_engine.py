@@ -25,7 +25,9 @@ def _split_planes(w: torch.Tensor):
 class _ConvW:
     """[Cout, Cin, k, k] fp32 -> (hi, lo) bf16 planes [k*k][Npad][Cin] + fp32 bias."""
 
-    def __init__(self, conv):
+    def __init__(self, conv, wino=None):
+        """wino: also build the Winograd-transformed copy (None: only when LGEN_VQ_WINO=1 asks for that form: the copy is 16/9 of
+        the (hi, lo) weights and would sit in HBM unused otherwise)."""
         w = conv.weight.detach().float()
         cout, cin, k, _ = w.shape
         blk = 128 if cout >= 128 else (64 if cout >= 64 else 16)
@@ -49,7 +51,9 @@ class _ConvW:
         # Winograd F(2x2, 3x3) form (lgen_conv_wino): U = G g G^T per (cout, cin), 16 "positions" pi * 4 + pj in place of the 9 taps,
         # evaluated in fp64 and rounded once to fp32, then the same (hi, lo) split and fragment order
         self.wino = None
-        if k == 3 and cout % 128 == 0 and cpad % 32 == 0 and cin == cpad:
+        if wino is None:
+            wino = os.environ.get("LGEN_VQ_WINO", "0") == "1"
+        if wino and k == 3 and cout % 128 == 0 and cpad % 32 == 0 and cin == cpad:
             G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64, device=w.device)
             U = (G @ w.double() @ G.t()).float()                                   # [cout][cin][4][4]
             ut = U.permute(2, 3, 0, 1).reshape(16, cout, cin).contiguous()

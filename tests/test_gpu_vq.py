@@ -385,8 +385,8 @@ def test_conv_wino_vs_fp32_reference(B, H, W, Cin, Cout, ups, res, gn):
     cv = Cv()
     cv.weight = (_rand((Cout, Cin, 3, 3), 4) / (Cin * 9) ** 0.5).to(dev)
     cv.bias = (0.1 * _rand((Cout,), 5)).to(dev)
-    cw = _ConvW(cv)
-    assert cw.wino is not None
+    cw = _ConvW(cv, wino=True)
+    assert cw.wino is not None and _ConvW(cv, wino=False).wino is None
     Hs, Ws = (H // 2, W // 2) if ups else (H, W)
     x = _rand((B, Hs, Ws, Cin), 6) * 1.5 + 0.3
     r = _rand((B, H, W, Cout), 7) if res else None

@@ -14,7 +14,7 @@ lib.lgen_debug_set_conv_fused_variant(1 if variant == 2 else variant)
 torch.manual_seed(0)
 class Cv: pass
 cv = Cv(); cv.weight = (torch.randn(Cout, Cin, 3, 3) / (Cin * 9) ** 0.5).to(dev); cv.bias = torch.zeros(Cout, device=dev)
-cw = _ConvW(cv)
+cw = _ConvW(cv, wino=(variant == 2))
 x = torch.randn(B, H, H, Cin, device=dev)
 if abl & 8:  # zero operands: the DVFS / power check of the MI355X guide
     x.zero_(); cw.frag.zero_()

@@ -440,11 +440,12 @@ def live_traffic(rows, timeout_s=150):
 
 
 def other_configs(timeout_s=420):
-    """BASELINE configs 4 and 5 next to the headline: `bench.py --config N` (the schedule of profiles/r0x_bench_configN.json, fewer
-    steps) as a child process each, parsed from its JSON line.  A tested GEMM schedule is required there too (the child refuses an
-    untested one before timing).  Returns {"config4": {...}, "config5": {...}}; a failed pass is reported as such, never invented."""
+    """BASELINE configs 3 (its per-GPU shape: GPT-XXL, batch 32 of the 256 over 8 GPUs), 4 and 5 next to the headline: `bench.py
+    --config N` (the schedule of profiles/r0x_bench_configN.json, fewer steps) as a child process each, parsed from its JSON line.  A tested GEMM schedule is required there too (the child refuses an
+    untested one before timing).  Returns {"config3": {...}, "config4": {...}, "config5": {...}}; a failed pass is reported as such,
+    never invented."""
     out = {}
-    for c, steps, warm in ((4, 8, 2), (5, 12, 4)):
+    for c, steps, warm in ((3, 12, 4), (4, 8, 2), (5, 12, 4)):
         cmd = [sys.executable, os.path.abspath(__file__), "--config", str(c), "--steps", str(steps), "--warmup", str(warm),
                "--no-cpu-baseline", "--no-live-traffic", "--no-solo", "--no-one-chain", "--no-roofline"]
         t0 = time.time()

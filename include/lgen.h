@@ -10,10 +10,10 @@
  * inside the library: (1) one-shot `hipFuncSetAttribute` flags for the kernels that need more than 64 KiB of LDS (set on first use
  * for the current device) and the cached CU count of the persistent attention form; (2) the development switches of the
  * `lgen_debug_*` section at the end of this header (process-wide ints read at launch time, never set by the product path) and the
- * LGEN_GEMM_STEADY / LGEN_TILE_ABLATE / LGEN_WINO_ABLATE / LGEN_ATTN_CLAMP environment variables (read at launch = capture time;
- * bit-identical results / timing ablations / the pre-round-5 key loads of the decode attention for A/B runs).  ABI v8 = v7 +
- * lgen_conv_wino, and a K/V row stride that may be smaller than the lane group hdp (lgen_gemm_qkv_rope).  Each entry point cites the
- * reference op sequence it replaces (paths relative to the reference repository root).
+ * LGEN_GEMM_STEADY / LGEN_TILE_ABLATE environment variables (read at launch = capture time; bit-identical results / timing
+ * ablations).  ABI v8 = v7 + a K/V row stride that may be smaller than the lane group hdp (lgen_gemm_qkv_rope); ABI v9 = v8 minus
+ * lgen_conv_wino (the Winograd experiment of round 5 left the product library: tools/experiments/conv_wino/).  Each entry point
+ * cites the reference op sequence it replaces (paths relative to the reference repository root).
  *
  * Fragment-packed layouts ("chunk" = 1 KiB = [16 rows][KC k] in MFMA operand order, lane =
  * g*16 + r holds row r, k-slice g*EPL..+EPL; bf16: KC=32, EPL=8; fp32: KC=16, EPL=4):
@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LGEN_ABI_VERSION 8
+#define LGEN_ABI_VERSION 9
 #define LGEN_BF16 0
 #define LGEN_F32 1
 #define LGEN_F16 2   /* fp16 storage: BF16's layouts (KC = 32, EPL = 8), IEEE half rounding, v_mfma_f32_16x16x32_f16 */
@@ -242,17 +242,6 @@ int lgen_conv_fused_bn(int Cout);
 int lgen_conv_fused(const float* x_nhwc, const float* gn_coef, int swish, const void* w_frag, const float* bias,
                     const float* res, float* out, float* stats_partial, int B, int H, int W, int Cin, int Cout, int Npad,
                     int ksize, int upsample, int out_nchw, void* stream);
-
-/* The same operation for 3x3 convolutions in Winograd F(2x2, 3x3) form (round 5, ABI v8; csrc/conv_wino.hip): 16 instead of 36
- * MFMA products per 2 x 2 output block and input channel, transforms in fp32, products in the same 3-pass split-bf16 form on the
- * transformed operands.  Same argument meaning as lgen_conv_fused (x read once as fp32 NHWC [B][H>>upsample][W>>upsample][Cin],
- * gn_coef / swish applied on the tile load, bias, res, NHWC out, stats_partial [B][(H/8)*(W/16)][Cout/4][2]) for the shapes the
- * form covers: H % 8 == 0, W % 16 == 0, Cin % 32 == 0, Cout % 128 == 0; LGEN_ERR_UNSUPPORTED otherwise (use lgen_conv_fused).
- * u_frag: the transformed weights U = G g G^T (g = weight[cout][cin] 3x3, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]), (hi, lo)
- * bf16 split, in MFMA fragment order [Cout/128][Cin/32][16 positions pi*4+pj][2 planes][8 cout tiles][64 lanes][8]. */
-int lgen_conv_wino(const float* x_nhwc, const float* gn_coef, int swish, const void* u_frag, const float* bias,
-                   const float* res, float* out, float* stats_partial, int B, int H, int W, int Cin, int Cout,
-                   int upsample, void* stream);
 
 /* GroupNorm(32, C, eps) statistics -> per-channel (scale, shift) = (rstd*gamma, beta - rstd*gamma*mean), coef [B][C][2].
  * Source: partial != NULL: the tile partials of lgen_conv_fused ([B][ntiles][quad_stride][2] = (sum, M2 about the partial's

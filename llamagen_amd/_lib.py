@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblgen_hip.so")
 BF16, F32, F16 = 0, 1, 2
 EPI_ROWS, EPI_PACKED, EPI_GELU, EPI_RES, EPI_SWIGLU, EPI_QKV = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 8
+ABI_VERSION = 9
 SSQ_STRIDE = 256  # LGEN_SSQ_STRIDE: floats per row of a fused-RMSNorm statistics array
 ERR_UNSUPPORTED = -2
 
@@ -59,7 +59,6 @@ SIGNATURES = {
     "lgen_softmax_split": [_P, _P, _P, _I, _I, _I, _P],
     "lgen_conv_fused_bn": [_I],
     "lgen_conv_fused": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
-    "lgen_conv_wino": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "lgen_gn_finalize": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
     "lgen_conv_igemm": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _c.c_longlong, _F, _P],
 }

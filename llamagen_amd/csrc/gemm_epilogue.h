@@ -212,9 +212,8 @@ LGEN_DEV void epilogue(const GemmArgs& a, int nt, int mt, int lane, f32x4_t v, f
         if (sec < 2) {  // 2-D RoPE on interleaved (even, odd) pairs, fp32, one rounding
             const float fx = __uint_as_float(aux.x), fy = __uint_as_float(aux.y);
             const float fz = __uint_as_float(aux.z), fw = __uint_as_float(aux.w);
-            float y0 = x0 * fx - x1 * fy, y1 = x1 * fx + x0 * fy;
-            float y2 = x2 * fz - x3 * fw, y3 = x3 * fz + x2 * fw;
-            x0 = y0; x1 = y1; x2 = y2; x3 = y3;
+            rope_pair(x0, x1, fx, fy);
+            rope_pair(x2, x3, fz, fw);
         }
         // (pointers and strides read into values FIRST: selecting between the ADDRESSES of kernel-argument fields made the compiler
         // spill them to 40 B of scratch once `a` arrived through a helper's reference)

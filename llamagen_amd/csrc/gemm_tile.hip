@@ -405,9 +405,8 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_tile_kernel(GemmArgs
                     if (qc.sec < 2) {  // 2-D RoPE on interleaved (even, odd) pairs, fp32, one rounding (gpt.py:420-430)
                         const float fx = __uint_as_float(rope[j].x), fy = __uint_as_float(rope[j].y);
                         const float fz = __uint_as_float(rope[j].z), fw = __uint_as_float(rope[j].w);
-                        const float y0 = x0 * fx - x1 * fy, y1 = x1 * fx + x0 * fy;
-                        const float y2 = x2 * fz - x3 * fw, y3 = x3 * fz + x2 * fw;
-                        x0 = y0; x1 = y1; x2 = y2; x3 = y3;
+                        rope_pair(x0, x1, fx, fy);
+                        rope_pair(x2, x3, fz, fw);
                     }
                     if (m < a.M) {
                         if (qc.sec == 0) {

@@ -251,7 +251,6 @@ struct AttnArgs {
     float sf;            // sqrt(1/sqrt(hd))
     int kvs;             // elements between consecutive cache rows (hdp, or 2*hdp for an interleaved K|V slab)
     int mask_len;        // only keys < mask_len consult the mask row (t2i: the caption prefix); the rest is pure causal
-    int no_clamp;        // development A/B (LGEN_ATTN_CLAMP=0): key loads clamped to the slab's last slot as before round 5
 };
 
 // HPW (round 3): (batch row, head) pairs per workgroup.  At 256 chain rows the grid is 4096 (b, h) pairs; dispatching that many
@@ -298,7 +297,7 @@ __global__ __launch_bounds__(64 * ATT_NW * HPW, (ATT_CH <= 2 ? 4 : 2)) void attn
     const int pos = a.pos_ptr[b * a.pos_stride];
     const int kvlen = pos + 1;
     const int ngroups = (kvlen + GK - 1) / GK;
-    smax = (pos < smax && !a.no_clamp) ? pos : smax;
+    smax = pos < smax ? pos : smax;
     float qf[EPL];
     D::unpack(qv, qf);
 #pragma unroll
@@ -426,7 +425,7 @@ __global__ __launch_bounds__(64 * NWV) void attn_decode_persist_kernel(AttnArgs 
     const int pos = *a.pos_ptr;
     const int kvlen = pos + 1;
     const int ngroups = (kvlen + GK - 1) / GK;
-    smax = (pos < smax && !a.no_clamp) ? pos : smax;
+    smax = pos < smax ? pos : smax;
     int li = gw, lg = 0;                      // load cursor: the group after the one just requested
     auto advance = [&](int& item, int& g) {
         if (++g == ngroups) { g = 0; item += total_waves; }
@@ -526,8 +525,7 @@ static int attn_decode_impl(const void* q, const void* k_cache, const void* v_ca
                             const int* pos_ptr, int pos_stride, const unsigned char* mask, int mask_len, int B2, int MTs,
                             int n_head, int hd, int hdp, int S8, int kv_row_stride, int dtype, int variant_arg, void* stream) {
     AttnArgs a{q, k_cache, v_cache, out_packed, pos_ptr, pos_stride, mask, n_head, hd, hdp, S8, MTs, 0.f,
-               kv_row_stride > 0 ? kv_row_stride : hdp, mask_len > 0 ? mask_len : S8, 0};
-    if (const char* e = getenv("LGEN_ATTN_CLAMP")) a.no_clamp = atoi(e) == 0;   // read per call: A/B inside one process / one box
+               kv_row_stride > 0 ? kv_row_stride : hdp, mask_len > 0 ? mask_len : S8};
     if (variant_arg < -1 || variant_arg > 14) return LGEN_ERR_BAD_ARG;
     a.sf = sqrtf(1.0f / sqrtf((float)hd));
     hipStream_t st = (hipStream_t)stream;
@@ -655,8 +653,7 @@ __global__ __launch_bounds__(256) void rope_append_prefill_kernel(const uint4* _
             float x0 = f[e], x1 = f[e + 1];
             if (sec < 2) {  // interleaved (even, odd) pairs, fp32, one rounding at the store
                 const float2 cs = *(const float2*)(freqs + ((size_t)(pos0 + t) * (hd >> 1) + (dd >> 1)) * 2);
-                const float y0 = x0 * cs.x - x1 * cs.y, y1 = x1 * cs.x + x0 * cs.y;
-                x0 = y0; x1 = y1;
+                rope_pair(x0, x1, cs.x, cs.y);
             }
             if (sec == 0) {
                 D::st(qrows, ((size_t)r * H + head) * hdp + dd, x0);

@@ -208,6 +208,22 @@ struct F16 {
     }
 };
 
+// 2-D RoPE rotation of one interleaved (even, odd) pair (gpt.py:420-430): fp32, four separately rounded products, one add, one sub.
+// Kept SCALAR on purpose.  Left to itself hipcc's SLP vectoriser pairs the products into packed-fp32 instructions with CROSSED operand
+// selection (`v_pk_mul_f32 v[44:45], v[138:139], v[30:31] op_sel:[0,1] op_sel_hi:[0,0]`: low result = src0.lo * src1.HI), and on MI355X
+// that instruction intermittently returns a wrong low product in lanes 48-63 -- the wrong q / k elements of GPUTEST_r05
+// (tools/isa_run_qkv.py reproduces it, profiles/r06_isa_ab*.log).  The empty asm statements make every
+// intermediate an opaque value, so there is no vectorisable tree; tools/isa_lint.py (run by tests/test_abi.py on the built library)
+// fails the build if a crossed packed-fp32 instruction shows up anywhere.
+LGEN_DEV void rope_pair(float& x0, float& x1, float c, float s) {
+    float a = x0 * c, b = x1 * s, e = x1 * c, f = x0 * s;
+    asm volatile("" : "+v"(a), "+v"(b), "+v"(e), "+v"(f));
+    float y0 = a - b, y1 = e + f;
+    asm volatile("" : "+v"(y0), "+v"(y1));
+    x0 = y0;
+    x1 = y1;
+}
+
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 LGEN_DEV uint4 ldg_nt(const uint4* p) {  // streamed-once data (weights): non-temporal
     u32x4_t v = __builtin_nontemporal_load((const u32x4_t*)p);

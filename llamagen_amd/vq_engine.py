@@ -25,9 +25,7 @@ def _split_planes(w: torch.Tensor):
 class _ConvW:
     """[Cout, Cin, k, k] fp32 -> (hi, lo) bf16 planes [k*k][Npad][Cin] + fp32 bias."""
 
-    def __init__(self, conv, wino=None):
-        """wino: also build the Winograd-transformed copy (None: only when LGEN_VQ_WINO=1 asks for that form: the copy is 16/9 of
-        the (hi, lo) weights and would sit in HBM unused otherwise)."""
+    def __init__(self, conv):
         w = conv.weight.detach().float()
         cout, cin, k, _ = w.shape
         blk = 128 if cout >= 128 else (64 if cout >= 64 else 16)
@@ -48,22 +46,6 @@ class _ConvW:
         pk = lambda q: q.view(k * k, self.fnpad // bn, bn // 16, 16, cpad // 32, 4, 8).permute(1, 4, 0, 2, 5, 3, 6)
         self.frag = torch.stack([pk(fh), pk(fl)], dim=3).contiguous()  # [nb][kc][tap][plane][j][g][r][8]
         self.bn = bn
-        # Winograd F(2x2, 3x3) form (lgen_conv_wino): U = G g G^T per (cout, cin), 16 "positions" pi * 4 + pj in place of the 9 taps,
-        # evaluated in fp64 and rounded once to fp32, then the same (hi, lo) split and fragment order
-        self.wino = None
-        if wino is None:
-            wino = os.environ.get("LGEN_VQ_WINO", "0") == "1"
-        if wino and k == 3 and cout % 128 == 0 and cpad % 32 == 0 and cin == cpad:
-            G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64, device=w.device)
-            U = (G @ w.double() @ G.t()).float()                                   # [cout][cin][4][4]
-            ut = U.permute(2, 3, 0, 1).reshape(16, cout, cin).contiguous()
-            uh, ul = _split_planes(ut)
-            # kernel order (csrc/conv_wino.hip): [nb][kc][sub-step ss = pj * 4 + jt][wave = pi * 2 + wn][hi|lo][g][r][8], where the
-            # fragment is position pi * 4 + pj, cout tile wn * 4 + jt of the 128-channel block -- the (hi, lo) pair one wave needs in
-            # one sub-step is contiguous (its private DMA)
-            up = torch.stack([uh, ul])                                              # [plane][position][cout][cin]
-            up = up.view(2, 4, 4, cout // 128, 2, 4, 16, cin // 32, 4, 8)           # plane, pi, pj, nb, wn, jt, r, kc, g, e
-            self.wino = up.permute(3, 7, 2, 5, 1, 4, 0, 8, 6, 9).contiguous()       # nb, kc, pj, jt, pi, wn, plane, g, r, e
 
 
 class _GNW:
@@ -89,7 +71,6 @@ class VQEngine:
             self.lib.lgen_debug_set_vq_nt(int(os.environ["LGEN_VQ_NT"]))
         self.dev = model.post_quant_conv.weight.device
         self.fused = os.environ.get("LGEN_VQ_FUSED", "1") != "0"  # lgen_conv_fused where the shape allows it
-        self.wino = os.environ.get("LGEN_VQ_WINO", "0") == "1"    # lgen_conv_wino (Winograd F(2x2, 3x3)): opt-in until it beats the direct form
         if os.environ.get("LGEN_CF_VARIANT") is not None:  # tuning knob, see lgen_debug_set_conv_fused_variant in lgen.h
             self.lib.lgen_debug_set_conv_fused_variant(int(os.environ["LGEN_CF_VARIANT"]))
         cfg = model.config
@@ -184,13 +165,6 @@ class VQEngine:
         out = torch.empty(B * H * W * cw.cout, dtype=torch.float32, device=self.dev)
         ntiles = (H // 8) * ((W + 15) // 16)
         part = torch.empty(B * ntiles * (cw.fnpad // 4) * 2, dtype=torch.float32, device=self.dev) if want_part else None
-        if self.wino and cw.wino is not None and W % 16 == 0 and not out_nchw:
-            rc = self.lib.lgen_conv_wino(L.ptr(x.t), L.ptr(coef), 1 if swish else 0, L.ptr(cw.wino), L.ptr(cw.bias),
-                                         L.ptr(res.t if isinstance(res, _Act) else res), L.ptr(out), L.ptr(part), B, H, W, cw.cin,
-                                         cw.cout, 1 if upsample else 0, L.stream())
-            if rc != L.ERR_UNSUPPORTED:
-                L.check(rc, "conv_wino")
-                return _Act(out, part, ntiles, cw.fnpad // 4, W)
         L.check(self.lib.lgen_conv_fused(L.ptr(x.t), L.ptr(coef), 1 if swish else 0, L.ptr(cw.frag), L.ptr(cw.bias),
                                          L.ptr(res.t if isinstance(res, _Act) else res), L.ptr(out), L.ptr(part), B, H, W, cw.cin,
                                          cw.cout, cw.fnpad, cw.k, 1 if upsample else 0, 1 if out_nchw else 0, L.stream()),

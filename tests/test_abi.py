@@ -32,7 +32,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/ but not exported"
         assert s in _lib.SIGNATURES, f"{s} has no ctypes signature"
-    assert lib.lgen_abi_version() == _lib.ABI_VERSION == 8
+    assert lib.lgen_abi_version() == _lib.ABI_VERSION == 9
 
 
 def test_header_arg_counts_match_ctypes_signatures():
@@ -249,6 +249,25 @@ def test_hot_kernels_have_no_register_spills():
         members = [n for n in kernels if family in n]
         assert members, family
         assert all(kernels[n].get("ScratchSize", 0) == 0 for n in members), family
+
+
+def test_device_code_has_no_crossed_packed_fp32_instruction():
+    """Round 6: on MI355X `v_pk_mul_f32 ... op_sel:[0,1] op_sel_hi:[0,0]` -- a packed-fp32 multiply whose LOW
+    result reads the HIGH register of a VGPR pair, made by hipcc's SLP vectoriser out of the RoPE rotation -- intermittently returned a
+    wrong low product in lanes 48-63 (the wrong q elements of GPUTEST_r05; reproduced and bisected at ISA level with
+    tools/isa_run_qkv.py).  The sources keep the rotation scalar (lgen_common.h: rope_pair); this test disassembles the device code
+    of the BUILT library and fails when any kernel contains a packed-fp32 instruction with crossed VGPR operand selection."""
+    import shutil
+    from tools import isa_lint
+    if not os.path.exists(isa_lint.LLVM + "/llvm-objdump"):
+        pytest.skip("no llvm-objdump (the lint runs where the library is built)")
+    from llamagen_amd import _lib
+    hits, n_pk = isa_lint.lint(isa_lint.disassemble(_lib.LIB_PATH))
+    assert n_pk > 1000, n_pk          # the disassembly really covers the device code
+    assert not hits, {k: v[:2] for k, v in list(hits.items())[:5]}
+    assert isa_lint.crossed(isa_lint.PK.search("v_pk_mul_f32 v[44:45], v[138:139], v[30:31] op_sel:[0,1] op_sel_hi:[0,0]"))
+    assert not isa_lint.crossed(isa_lint.PK.search("v_pk_mul_f32 v[76:77], s[30:31], v[0:1] op_sel:[1,0]"))
+    del shutil
 
 
 def test_graft_entry_build_passes():

@@ -1,0 +1,40 @@
+"""Determinism of every kernel family (round 6): the same launch repeated on poisoned output buffers must
+produce bit-identical results every time, and must not touch its inputs.
+
+GPUTEST_r05 failed on a wrong result that showed up in about one launch of three of one fp16 kernel
+(`gemm_kernel<F16,4,1,EPI_QKV>` at 192 rows: 16 q / k elements per hit) and in none of the others: a packed-fp32 multiply with
+crossed operand selection that MI355X occasionally gets wrong.  A parity test that launches a kernel once
+sees such a fault only by luck; this one launches every case of tools/stress_kernels.py (skinny GEMMs x epilogues x dtypes, fused
+RMSNorm forms, the big-M tile family at 256 / 640 rows, decode attention in both forms, sampler, rmsnorm) 200 times.
+tools/stress_kernels.py itself is the long form (5000 launches per case, fresh buffers, a second stream hammering HBM)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ITERS = 200
+
+
+@pytest.mark.parametrize("family", ["qkv_cases", "gemm_cases", "tile_cases", "attn_cases", "misc_cases"])
+def test_repeated_launches_are_bit_identical(family):
+    from tools import stress_kernels as S
+    assert torch.cuda.is_available(), "GPU tests need a real MI355X"
+    bad, ran = [], 0
+    for c in getattr(S, family)():
+        rec = S.run_case(c, ITERS, fresh=False, hammer=None)
+        if rec is None:
+            continue
+        ran += 1
+        if rec["bad_launches"] or not rec["inputs_intact"]:
+            bad.append(rec)
+    torch.cuda.empty_cache()
+    assert ran >= 2, (family, ran)
+    assert not bad, bad[:3]
+
+
+def test_qkv_rope_fp16_192_rows_harness_replay():
+    """The failing case's own harness (fresh host->device copies, pack, launch; bf16 and fp16 alternating like the suite's
+    neighbouring cases) 40 times: q / K / V rows and the packed operands bit-identical to the first pass of the same dtype."""
+    from tools import stress_kernels as S
+    rec = S.harness_qkv(40, None)
+    assert rec["bad_count"] == 0, rec["bad"][:3]

@@ -365,82 +365,6 @@ def test_conv_fused_vs_fp32_reference(B, H, W, Cin, Cout, k, ups, res, nchw, gn)
         np.testing.assert_allclose(c2[..., 1].cpu().numpy(), sh.float().numpy(), rtol=2e-5, atol=2e-5)
 
 
-@pytest.mark.parametrize("B,H,W,Cin,Cout,ups,res,gn", [
-    (2, 16, 32, 128, 128, 0, True, True),      # the 384 px level's shape class (ResnetBlock conv2: norm, swish, residual)
-    (1, 8, 16, 32, 128, 0, False, False),      # one tile, one chunk, plain conv
-    (2, 16, 16, 256, 256, 1, False, False),    # Upsample.conv: nearest-2x folded into the halo load, two 128-channel blocks
-    (1, 24, 48, 512, 256, 0, True, True),      # 16 input chunks, several tile rows / columns
-    (3, 8, 32, 128, 128, 0, False, True),      # no residual
-])
-def test_conv_wino_vs_fp32_reference(B, H, W, Cin, Cout, ups, res, gn):
-    """lgen_conv_wino (Winograd F(2x2, 3x3): fp32 transforms, 3-pass split-bf16 products on the transformed operands; same fusions
-    as lgen_conv_fused) against fp64 GroupNorm -> swish -> conv2d (vq_model.py:299-314, 354-378), against lgen_conv_fused on the
-    same operands, plus the tile partials against the statistics of the stored output."""
-    from llamagen_amd.vq_engine import _ConvW
-    L, dev = _L(), _dev()
-    lib = L.lib()
-
-    class Cv:
-        pass
-    cv = Cv()
-    cv.weight = (_rand((Cout, Cin, 3, 3), 4) / (Cin * 9) ** 0.5).to(dev)
-    cv.bias = (0.1 * _rand((Cout,), 5)).to(dev)
-    cw = _ConvW(cv, wino=True)
-    assert cw.wino is not None and _ConvW(cv, wino=False).wino is None
-    Hs, Ws = (H // 2, W // 2) if ups else (H, W)
-    x = _rand((B, Hs, Ws, Cin), 6) * 1.5 + 0.3
-    r = _rand((B, H, W, Cout), 7) if res else None
-    xd = x.to(dev).contiguous()
-    coef = None
-    xin = x.permute(0, 3, 1, 2).double()
-    if gn:
-        gamma, beta = 1 + 0.1 * _rand((Cin,), 8), 0.1 * _rand((Cin,), 9)
-        nchunk = 3
-        ws = torch.empty(B * nchunk * 64, dtype=torch.float64, device=dev)
-        st = torch.empty(B, 32, 2, device=dev)
-        L.check(lib.lgen_gn_stats(L.ptr(xd), L.ptr(ws), L.ptr(st), B, Hs * Ws, Cin, 1e-6, nchunk, L.stream()), "stats")
-        coef = torch.empty(B, Cin, 2, device=dev)
-        g_d, b_d = gamma.to(dev), beta.to(dev)
-        L.check(lib.lgen_gn_finalize(0, L.ptr(st), L.ptr(g_d), L.ptr(b_d), L.ptr(coef), B, Cin, 0, 0, Hs * Ws, 0, 1e-6, L.stream()), "fin")
-        xin = F.group_norm(xin, 32, gamma.double(), beta.double(), eps=1e-6)
-        xin = xin * torch.sigmoid(xin)
-    if ups:
-        xin = xin.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
-    ref = F.conv2d(xin, cv.weight.cpu().double(), cv.bias.cpu().double(), padding=1).float()
-    if res:
-        ref = ref + r.permute(0, 3, 1, 2)
-    r_d = r.to(dev).contiguous() if res else None
-    tiles_x = W // 16
-    ntiles = (H // 8) * tiles_x
-    out = torch.full((B * H * W * Cout,), float("nan"), device=dev)
-    part = torch.full((B, ntiles, Cout // 4, 2), float("nan"), device=dev)
-    L.check(lib.lgen_conv_wino(L.ptr(xd), L.ptr(coef), 1 if gn else 0, L.ptr(cw.wino), L.ptr(cw.bias), L.ptr(r_d), L.ptr(out),
-                               L.ptr(part), B, H, W, Cin, Cout, ups, L.stream()), "conv_wino")
-    out_f = torch.full((B * H * W * Cout,), float("nan"), device=dev)
-    part_f = torch.full((B, ntiles, cw.fnpad // 4, 2), float("nan"), device=dev)
-    L.check(lib.lgen_conv_fused(L.ptr(xd), L.ptr(coef), 1 if gn else 0, L.ptr(cw.frag), L.ptr(cw.bias), L.ptr(r_d), L.ptr(out_f),
-                                L.ptr(part_f), B, H, W, Cin, Cout, cw.fnpad, 3, ups, 0, L.stream()), "conv_fused")
-    got = out.cpu().view(B, H, W, Cout).permute(0, 3, 1, 2)
-    got_f = out_f.cpu().view(B, H, W, Cout).permute(0, 3, 1, 2)
-    assert torch.isfinite(got).all()
-    scale = max(1.0, ref.abs().max().item())
-    err, err_f = (got - ref).abs().max().item(), (got_f - ref).abs().max().item()
-    assert err < 1e-4 * scale, (err, err_f)         # (the direct form holds 6e-5: the transformed operands carry ~1.5 x its rounding)
-    assert (got - got_f).abs().max().item() < 1.2e-4 * scale
-    gq = got.double()
-    pc = part.cpu().double()
-    nq = Cout // 4
-    for ty in range(H // 8):
-        for tx in range(tiles_x):
-            blk = gq[:, :, ty * 8:ty * 8 + 8, tx * 16:tx * 16 + 16].reshape(B, nq, 4, -1).reshape(B, nq, -1)
-            S = blk.sum(-1)
-            M2 = ((blk - blk.mean(-1, keepdim=True)) ** 2).sum(-1)
-            np.testing.assert_allclose(pc[:, ty * tiles_x + tx, :, 0].numpy(), S.numpy(), rtol=1e-5, atol=1e-3)
-            np.testing.assert_allclose(pc[:, ty * tiles_x + tx, :, 1].numpy(), M2.numpy(), rtol=1e-4, atol=1e-3)
-    # shapes the form does not cover are refused, not mangled
-    assert lib.lgen_conv_wino(L.ptr(xd), 0, 0, L.ptr(cw.wino), 0, 0, L.ptr(out), 0, B, H, W + 8, Cin, Cout, ups, L.stream()) == L.ERR_UNSUPPORTED
-
-
 def test_fused_groupnorm_statistics_survive_a_large_offset():
     """ADVICE (round 2): sum / sum-of-squares partials lose the variance to cancellation when |mean| >> std.  A 1x1 convolution with
     tiny weights and a large bias stores values 60 +- 0.02; the (sum, M2) partials + Chan combine must still give the fp64

@@ -434,11 +434,23 @@ __global__ __launch_bounds__(64 * NWV) void attn_decode_persist_kernel(AttnArgs 
 
     int ci = gw, cg = 0;                      // compute cursor
     float qf[EPL], m_run = -1e30f, l_run = 0.f, acc[EPL];
-    uint4 qn = qv;
+    uint4 qn = qv, qraw = qv;
+    // 16-bit storage (round 6): q . k as packed dot products on the RAW operands (v_dot2c_f32_bf16 / v_dot2_f32_f16: 4 instructions
+    // per 8 elements instead of 8 unpacks + 8 multiplies + 8 fmas), scaled once by sf^2 -- the products of two 8- / 11-bit
+    // mantissas are exact in fp32, so this differs from the reference's sum of fl(q sf) * fl(k sf) (ATen's sqrt(scale) on both operands)
+    // by fp32 round-off only, like any other summation order.  The kernel spent 44 % of its wave cycles issuing VALU
+    // (profiles/r06_sq_pmc.csv) -- cycles the other chain's GEMM waves on the same SIMDs wait for.
+    const float sf2 = a.sf * a.sf;
     auto begin_item = [&]() {
-        D::unpack(qn, qf);
+        if constexpr (D::ESZ == 2) {
+            qraw = qn;
+        } else {
+            D::unpack(qn, qf);
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) { qf[e] *= a.sf; acc[e] = 0.f; }
+            for (int e = 0; e < EPL; ++e) qf[e] *= a.sf;
+        }
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
         m_run = -1e30f; l_run = 0.f;
         const int nxt = ci + total_waves;     // q of the following item: one whole item ahead
         qn = ((const uint4*)a.q)[(size_t)(nxt < items ? nxt : ci) * lpr + part];
@@ -451,11 +463,15 @@ __global__ __launch_bounds__(64 * NWV) void attn_decode_persist_kernel(AttnArgs 
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
             const int key = cg * GK + j * KPL + kin;
-            float kf[EPL];
-            D::unpack(KB[j], kf);
             float dot = 0.f;
+            if constexpr (D::ESZ == 2) {
+                dot = D::dot8(KB[j], qraw) * sf2;
+            } else {
+                float kf[EPL];
+                D::unpack(KB[j], kf);
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) dot = fmaf(qf[e], kf[e] * a.sf, dot);
+                for (int e = 0; e < EPL; ++e) dot = fmaf(qf[e], kf[e] * a.sf, dot);
+            }
             dot = group_sum<LPK>(dot);
             bool vis = key < kvlen;
             if (pm && vis && key < a.mask_len) vis = pm[key] != 0;

@@ -93,6 +93,13 @@ struct BF16 {
         for (int e = 0; e < 8; ++e) f[e] = f[e] * wf[e];
         return pack(f);
     }
+    // sum of the 8 products of two packed operands, fp32 accumulation (v_dot2c_f32_bf16 x 4; bf16 x bf16 products are exact in fp32)
+    LGEN_DEV static float dot8(const uint4& a, const uint4& b) {
+        float d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a.x), __builtin_bit_cast(bf16x2_t, b.x), 0.f, false);
+        d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a.y), __builtin_bit_cast(bf16x2_t, b.y), d, false);
+        d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a.z), __builtin_bit_cast(bf16x2_t, b.z), d, false);
+        return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a.w), __builtin_bit_cast(bf16x2_t, b.w), d, false);
+    }
     LGEN_DEV static f32x4_t mma(const uint4& a, const uint4& b, f32x4_t c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
                                                         __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
@@ -202,6 +209,13 @@ struct F16 {
 #pragma unroll
         for (int e = 0; e < 8; ++e) f[e] = f[e] * wf[e];
         return pack(f);
+    }
+    LGEN_DEV static float dot8(const uint4& a, const uint4& b) {   // v_dot2_f32_f16 x 4
+        typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+        float d = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, a.x), __builtin_bit_cast(f16x2_t, b.x), 0.f, false);
+        d = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, a.y), __builtin_bit_cast(f16x2_t, b.y), d, false);
+        d = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, a.z), __builtin_bit_cast(f16x2_t, b.z), d, false);
+        return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, a.w), __builtin_bit_cast(f16x2_t, b.w), d, false);
     }
     LGEN_DEV static f32x4_t mma(const uint4& a, const uint4& b, f32x4_t c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);

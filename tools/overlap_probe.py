@@ -19,13 +19,14 @@ from llamagen_amd import _lib as L  # noqa: E402
 ROWS = int(os.environ.get("ROWS", "256"))
 POS = int(os.environ.get("POS", "300"))
 REPS = 30
+ATTN_VARIANT = int(os.environ.get("ATTN_VARIANT", "-1"))   # lgen_attn_decode variant of graph A (-1 = the library's choice)
 
 
 def attn_only(e):
     lib, st = e.lib, L.stream()
     for i in range(e.L):
         L.check(lib.lgen_attn_decode(L.ptr(e.qbuf), L.ptr(e.k_cache[i]), L.ptr(e.v_cache[i]), L.ptr(e.ap), L.ptr(e.state), 0, 0,
-                                     e.B2, e.MTs, e.H, e.hd, e.hdp, e.S8, e.kvs, e.dt, -1, st), "attn")
+                                     e.B2, e.MTs, e.H, e.hd, e.hdp, e.S8, e.kvs, e.dt, ATTN_VARIANT, st), "attn")
 
 
 def gemms_only(e):

@@ -72,11 +72,17 @@ def plan_schedule(args, B, N, T):
         want = max(1, min(10, (args.steps + 1) // 2))
         bpc = want if (want <= 6 or want == 10) else 6
     elif args.config == 3:
-        # GPT-XXL: two chains of up to six batches (384 rows) -- 42.0 img/s against 39.2 for three chains of four (round 4, same box
-        # class, profiles/r04_bench_config3.json); 2 x 6 x (10.6 GB of KV + 1.2 GB of noise) = 142 GB resident
-        bpc = max(1, min(6, (args.steps + 1) // 2))
+        # GPT-XXL: two chains of up to EIGHT batches (512 rows, round 6: 46.4 img/s against 43.9 for two chains of six and 39.2 for
+        # three chains of four, profiles/r06_widen.log); 2 x 8 x (10.6 GB of KV + 1.2 GB of noise) = 189 GB resident
+        bpc = max(1, min(8, (args.steps + 1) // 2))
+    elif args.config == 4:
+        # GPT-3B: two chains of four batches of 64 (512 rows; round 6: 31.1 img/s against 30.0 for 2 x 2 with the 256-row shapes;
+        # round 4 measured ONE chain of four at 25.2 against 28.2 for 2 x 2 -- two chains in flight matter more than the width)
+        bpc = 4 if args.steps >= 8 else 2
     else:
-        bpc = {4: 2, 5: 4}[args.config]   # GPT-3B: 4 batches x 1 chain measured 25.2 img/s against 28.2 for 2 x 2
+        # GPT-XL t2i: two chains of eight batches of 16 (256 rows: tile family; round 6: 20.0 img/s against 17.8 for three chains of
+        # four on the skinny kernels)
+        bpc = 8 if args.steps >= 16 else 4
     chains = (args.steps + bpc - 1) // bpc
     n_layer, n_head, dim = GPT_DIMS[CONFIGS[args.config]["gpt"]]
     kvs = -(-(dim // n_head) // 8) * 8   # elements between key rows: head_dim rounded up to one 16-byte piece (engine.py)
@@ -95,8 +101,10 @@ def plan_schedule(args, B, N, T):
         while args.lanes > 1 and args.lanes * per_chain > HBM_BUDGET_BYTES:
             args.lanes -= 1
     # per-rank HBM budget (the one-chain transparency leg needs one more chain's worth)
+    if not args.no_one_chain and args.lanes > 1 and (args.lanes + 1) * per_chain > HBM_BUDGET_BYTES + 25e9 >= args.lanes * per_chain:
+        args.no_one_chain = True   # the transparency leg would need a third chain's slabs: dropped for this schedule (the line then has no `images_per_s_with_one_chain_in_flight`)
     need = (args.lanes + (0 if (args.no_one_chain or args.lanes == 1) else 1)) * per_chain
-    if need > HBM_BUDGET_BYTES + 60e9:
+    if need > HBM_BUDGET_BYTES + 25e9:
         raise SystemExit(f"schedule needs {need / 1e9:.0f} GB of KV slabs + noise per GPU ({args.lanes} chains x {bpc} batches of {B}): "
                          f"over the {HBM_BUDGET_BYTES / 1e9:.0f} GB budget; lower --batches-per-chain or --lanes")
     return bpc, per_chain
@@ -445,7 +453,7 @@ def other_configs(timeout_s=420):
     untested one before timing).  Returns {"config3": {...}, "config4": {...}, "config5": {...}}; a failed pass is reported as such,
     never invented."""
     out = {}
-    for c, steps, warm in ((3, 12, 4), (4, 8, 2), (5, 12, 4)):
+    for c, steps, warm in ((3, 16, 4), (4, 8, 2), (5, 16, 4)):
         cmd = [sys.executable, os.path.abspath(__file__), "--config", str(c), "--steps", str(steps), "--warmup", str(warm),
                "--no-cpu-baseline", "--no-live-traffic", "--no-solo", "--no-one-chain", "--no-roofline"]
         t0 = time.time()
@@ -605,6 +613,7 @@ def main():
     # timed and on every rank alike (round 4 checked after the timed region, on rank 0 only: ADVICE r4).
     eng0 = pipe.lanes[0].gpt._engine
     gsched0, sched_tested, sched_source = eng0.gemm_schedule(), bool(eng0.tile_schedule_tested()), eng0.tile_schedule_source()
+    del eng0   # only the derived values stay: a live reference would keep lane 0's KV slabs + noise resident through the solo leg and other_configs()
     if not sched_tested and not args.allow_untested_schedule:
         raise SystemExit(f"GEMM schedule {gsched0} (source: {sched_source}) is not one tests/test_gpu_headline.py holds to the oracle "
                          "(--allow-untested-schedule to run it anyway)")
@@ -762,6 +771,18 @@ def main():
                                          "ms_per_decode_code": round(vq_ms, 2), "flop_per_image_fp32": C["vq_gflop"] * 1e9, "mfma_passes": 3,
                                          "hipblaslt_bf16_gemm_8192_random_TFLOPs": round(lib_tf, 1),
                                          "frac_of_that_measured_ceiling": round(tf / lib_tf, 4)}
+            # MFMA utilisation from COUNTERS (north_star; SURVEY 8d "Reporting"): the committed SQ pass of this round (profiles/r06_sq_pmc.json,
+            # tools/run_r6_sqpmc.sh -> tools/pmc_sq_summary.py): SQ_VALU_MFMA_BUSY_CYCLES over (1024 SIMDs x GRBM_GUI_ACTIVE per XCD)
+            try:
+                sq = json.load(open(os.path.join(ROOT, "profiles", SQ_PMC_JSON)))
+                for key, fam in (("roofline_gemm", "tile"), ("roofline_vq_decode", "conv_fused_kernel")):
+                    f = sq["families"].get(fam)
+                    if f and rows == 640 and args.config == 2:   # the pass ran the 640-row schedule of config 2
+                        res[key]["mfma_busy"] = f["mfma_busy"]
+                        res[key]["mfma_busy_by_trace_at_2.4GHz"] = f.get("mfma_busy_by_trace")
+                        res[key]["mfma_busy_source"] = f"profiles/{SQ_PMC_JSON}: {sq['formula']}"
+            except Exception:  # noqa: BLE001 -- no committed pass: the fields stay absent
+                pass
         solo_needed = world == 1 and bpc * args.lanes > 1 and not args.no_solo
         if world == 1 and not args.no_roofline and not args.no_live_traffic and "roofline" in res:
             # live counters: free the GPU memory of this process's pipeline first when the solo leg rebuilds it anyway
@@ -808,9 +829,10 @@ def main():
         dist.destroy_process_group()
 
 
-HBM_BUDGET_BYTES = 180e9   # KV slabs + noise of the chains in flight per GPU (288 GB HBM3E minus weights, decoder activations, slack)
+HBM_BUDGET_BYTES = 215e9   # KV slabs + noise of the chains in flight per GPU (288 GB HBM3E minus weights <= 6.2 GB, decoder activations <= 10 GB at 64 x 384 px, workspaces, slack); round 6: 180 -> 215 for two 512-row chains of GPT-XXL (196 GB) / GPT-3B (211 GB)
 MFMA_BF16_PEAK_TFLOPS = 2500.0
 PMC_JSON = "r05_pmc.json"
+SQ_PMC_JSON = "r06_sq_pmc.json"
 
 
 def PMC_POSITIONS(N, T=1):

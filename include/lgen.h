@@ -91,7 +91,12 @@ int lgen_gemm_max_kw(int epilogue_kind, int fused_norm, int mt, int nt);
  * SMALLER than the lane group hdp, down to hd rounded up to 8 elements (GPT-3B: hd 100 -> rows 104 elements = 13 x 16 B apart
  * instead of 128): the attention kernels still read hdp elements per key -- the lanes past the row read the first bytes of the
  * NEXT row, which multiply q's zero pad lanes (QK^T) or land in output elements >= hd that are never stored (PV) -- so every
- * cache must be followed by >= (hdp - kv_row_stride) readable, finite elements (the engine allocates that slack);
+ * cache must be followed by >= (hdp - kv_row_stride) readable, FINITE elements (the engine allocates that slack), every cache
+ * element a packed row's neighbours can be must be finite too (an Inf / NaN there times a zero pad lane is NaN: with fp16 storage
+ * keep appended keys finite), and the q rows given to lgen_attn_decode / lgen_attn_prefill must hold EXACT ZEROS in elements
+ * [hd, hdp) (the QKV epilogues of this library write them so; a caller that fills q itself must too).  kv_row_stride must be a
+ * multiple of the 16-byte piece (8 elements, 4 for fp32) and >= hd rounded up to it: every entry point that takes it returns
+ * LGEN_ERR_BAD_ARG otherwise (round 6: also lgen_rope_append_prefill / lgen_attn_prefill);
  * freqs [P][hd/2][2] fp32 from precompute_freqs_cis_2d (gpt.py:404-417); norm_w / ssq_in / ssq_parts / eps as
  * in lgen_gemm; passes as in lgen_gemm. */
 int lgen_gemm_qkv_rope(const void* wp, const void* xp, void* q_out, void* k_cache, void* v_cache, const float* freqs,

@@ -690,6 +690,10 @@ extern "C" int lgen_rope_append_prefill(const void* qkv_packed, void* q_rows, vo
     const int kcsz = dtype != LGEN_F32 ? 32 : 16;
     if ((3 * d) % kcsz || d != n_head * hd || hd % 2 || R > MTs * 16 || B2 < 1 || R % B2) return LGEN_ERR_BAD_ARG;
     const int kvs = kv_row_stride > 0 ? kv_row_stride : hdp;
+    {   // same key-row contract as lgen_attn_decode: whole 16-byte pieces, at least the head's valid elements apart
+        const int epl = dtype != LGEN_F32 ? 8 : 4;
+        if (kvs % epl || kvs < (hd + epl - 1) / epl * epl) return LGEN_ERR_BAD_ARG;
+    }
     const long long total = (long long)(3 * d / kcsz) * MTs * 64;
     const int blocks = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
     hipStream_t st = (hipStream_t)stream;
@@ -1028,6 +1032,10 @@ extern "C" int lgen_attn_prefill(const void* q_rows, const void* k_cache, const 
                                  int kv_row_stride, int dtype, void* stream) {
     if (T < 1 || T > S8 || (long long)B2 * T > (long long)MTs * 16) return LGEN_ERR_BAD_ARG;
     const int kvs = kv_row_stride > 0 ? kv_row_stride : hdp;
+    {
+        const int epl = dtype != LGEN_F32 ? 8 : 4;
+        if (kvs % epl || kvs < (hd + epl - 1) / epl * epl) return LGEN_ERR_BAD_ARG;
+    }
     const float sf = sqrtf(1.0f / sqrtf((float)hd));
     if (dtype == LGEN_BF16 && g_prefill_mfma && (hdp == 64 || hdp == 128) && kvs % 8 == 0 && (hd & 3) == 0) {
         dim3 grid(B2 * n_head, (T + 63) / 64);

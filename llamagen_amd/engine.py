@@ -94,15 +94,30 @@ TABLE_MODEL = (1024, 2816, 16384)   # (dim, ffn hidden, vocab) of GPT-L: the mod
 # (ADVICE round 4).  The family now depends on shapes only: tile wherever a table names a shape the library takes.
 MODEL_TILE_SCHEDULES = {
     TABLE_MODEL: TILE_SCHEDULES,
-    (1536, 4096, 16384): {   # GPT-XXL (config 3: two chains of six batches = 384 rows)
+    # Round 6: chains of >= 512 rows for the wide models (bench.py --config 3 / 4: two chains of eight batches of 32 / four batches of
+    # 64) with shapes MEASURED per model and width (tools/gemm_tile_sweep.py, profiles/r06_tile_sweep_{xxl,3b,xl}.log, us per launch):
+    # GPT-XXL 512 rows wqkv 24.0 (28.9 with the 256-row shape), w1||w3 26.1, wo 8.4, w2 19.6, lm_head 50.5; GPT-3B 512 rows wqkv 99.4,
+    # w1||w3 140.7 (153.3), wo 23.7 (32.8), w2 53.6 (75.0), lm_head 109.3 (114.8); GPT-XL 256 rows (config 5: two chains of eight
+    # batches of 16) wqkv 12.8 (skinny 15.4), wo 5.6 (7.3), w1||w3 14.8 (20.0), w2 13.3 (12.6), lm_head 24.5 (27.1).
+    (1536, 4096, 16384): {   # GPT-XXL (config 3)
         16: {"qkv": (4, 1, 1, 8, 2, 4, 4), "wo": (2, 2, 2, 2, 4, 4, 4), "w13": (4, 1, 2, 8, 2, 4, 4), "w2": (2, 2, 2, 2, 4, 4, 4),
+             "head": (4, 1, 2, 8, 2, 4, 4)},
+        32: {"qkv": (8, 1, 1, 6, 2, 4, 4), "wo": (2, 2, 2, 2, 4, 4, 4), "w13": (4, 1, 2, 8, 2, 4, 4), "w2": (2, 2, 2, 2, 4, 4, 4),
              "head": (4, 1, 2, 8, 2, 4, 4)}},
-    (3200, 8704, 16384): {   # GPT-3B (config 4: two chains of two batches of 64 = 256 rows)
+    (3200, 8704, 16384): {   # GPT-3B (config 4)
         16: {"qkv": (8, 1, 1, 6, 2, 4, 4), "wo": (2, 2, 2, 2, 4, 4, 4), "w13": (4, 1, 1, 6, 2, 4, 4), "w2": (2, 2, 2, 2, 4, 4, 4),
+             "head": (8, 1, 1, 8, 2, 4, 4)},
+        32: {"qkv": (8, 1, 1, 6, 2, 4, 4), "wo": (2, 2, 4, 2, 2, 4, 4), "w13": (4, 1, 2, 6, 2, 4, 4), "w2": (2, 2, 4, 2, 2, 4, 4),
+             "head": (4, 1, 2, 8, 2, 4, 4)}},
+    (1280, 3584, 16384): {   # GPT-XL (config 5, t2i)
+        16: {"qkv": (4, 1, 1, 4, 4, 4, 4), "wo": (2, 2, 2, 1, 4, 4, 4), "w13": (4, 1, 1, 8, 2, 4, 4), "w2": (2, 2, 2, 1, 4, 4, 4),
              "head": (8, 1, 1, 8, 2, 4, 4)}},
 }
-# (dim, F, V) -> keys of its table that an end-to-end oracle test runs (test_config{3,4}_..._shapes_bf16_vs_oracle[128]: 256-row chains)
-TESTED_MODEL_SCHEDULES = {TABLE_MODEL: TESTED_TILE_SCHEDULES, (1536, 4096, 16384): (16,), (3200, 8704, 16384): (16,)}
+# (dim, F, V) -> keys of its table that an end-to-end oracle test runs (tests/test_gpu_headline.py:
+# test_config{3,4}_..._shapes_bf16_vs_oracle[128] / [192]: 256- / 384-row chains; test_config{3,4,5}_wide_chain_shapes_bf16_vs_oracle:
+# the 512- / 512- / 256-row chains bench.py runs since round 6)
+TESTED_MODEL_SCHEDULES = {TABLE_MODEL: TESTED_TILE_SCHEDULES, (1536, 4096, 16384): (16, 32), (3200, 8704, 16384): (16, 32),
+                          (1280, 3584, 16384): (16,)}
 
 
 def tile_schedule_key(mts: int, table=None):
@@ -266,8 +281,8 @@ class DecodeEngine:
         if dtype == torch.bfloat16 and self.MTs >= 16 and self.use_tile and (self.d // 16) % 4 == 0 and self.d // 16 <= L.SSQ_STRIDE:
             auto = True
         env = os.environ.get("LGEN_FUSED_NORM")
-        self._fuse_env = env
-        self.fuse_norm = auto if env is None else env == "1"
+        self._fuse_env, self._fuse_auto, self._fuse_forced = env, auto, None   # `fuse_norm` is DERIVED from these + pos_rows (property below)
+        self._tile_refused = set()   # GEMM kinds whose table shape the library refused (LGEN_ERR_UNSUPPORTED): served by the skinny kernels, reported as such
         self.tile_override = {}      # kind ("qkv" | "wo" | "w13" | "w2" | "head") -> (mt, nt, kw)
         # tuning hook: LGEN_TILES="qkv=2,4,8;wo=4,1,8;w2=4,1,8" (e.g. fewer, fatter workgroups per GEMM so that the
         # kernels of several in-flight batches share the chip side by side instead of taking turns)
@@ -309,11 +324,29 @@ class DecodeEngine:
     def pos_rows(self, value):
         """Per-row positions (llamagen_amd/serve.py) keep wqkv on the skinny kernels, so the RMSNorm is fused only where the
         register-resident fused-norm GEMMs apply (d / 32 = 8 x 3..6): a wide model (GPT-3B) that fused because its chain is >= 256
-        rows would otherwise run the generic norm-prologue kernel, slower than stand-alone norm + the wide ring shapes."""
+        rows would otherwise run the generic norm-prologue kernel, slower than stand-alone norm + the wide ring shapes.
+        The fused / unfused choice is the `fuse_norm` property below -- nothing is flipped here (the flip used to stick
+        after serving); only the captured graphs of the other mode are dropped, in BOTH directions."""
+        before = self.fuse_norm if hasattr(self, "_fuse_auto") else None
         self._pos_rows = value
-        if value is not None and getattr(self, "_fuse_env", None) is None and hasattr(self, "_fuse_base") and self.fuse_norm != self._fuse_base:
-            self.fuse_norm = self._fuse_base
+        if before is not None and self.fuse_norm != before:
             self._graphs = {}
+
+    @property
+    def fuse_norm(self) -> bool:
+        """RMSNorm inside the consumer GEMMs?  LGEN_FUSED_NORM if set, else an explicit assignment (tests), else: with per-row
+        positions only where the register-resident fused-norm kernels apply (`_fuse_base`), otherwise wherever the chain width
+        / storage type allows (`_fuse_auto`).  gemm_schedule(), tile_schedule_tested() and the graph key read this."""
+        if self._fuse_env is not None:
+            return self._fuse_env == "1"
+        if self._fuse_forced is not None:
+            return self._fuse_forced
+        return self._fuse_base if self._pos_rows is not None else self._fuse_auto
+
+    @fuse_norm.setter
+    def fuse_norm(self, value):
+        self._fuse_forced = None if value is None else bool(value)
+        self._graphs = {}
 
     # ---- weights --------------------------------------------------------------------------
     def _sig(self, model):
@@ -411,6 +444,8 @@ class DecodeEngine:
         skinny kernels stay: chains of >= 256 rows, bf16, RMSNorm fused (the family's norm consumers read the producer's statistics),
         one position for all rows.  Measured on MI355X, GPT-L, 256 rows (tools/gemm_tile_sweep.py, us per launch, skinny -> tile):
         wqkv 10.2 -> 9.8, wo 4.85 -> 4.1, w1||w3 13.1 -> 10.6, w2 7.8 -> 7.7, lm_head 23.2 -> 20.9."""
+        if kind in self._tile_refused:
+            return None
         if kind in self.tile_shape_override:
             return self.tile_shape_override[kind]
         if not self.use_tile or self.MTs < 16 or self.dtype != torch.bfloat16 or not self.fuse_norm:
@@ -570,7 +605,7 @@ class DecodeEngine:
         return passes, 0
 
     # ---- launches -----------------------------------------------------------------------------
-    def gemm(self, wp, xp, out, M, mts, N, K, epi, tiles, norm_w=None, ssq_out=None, sched=None, tile=None):
+    def gemm(self, wp, xp, out, M, mts, N, K, epi, tiles, norm_w=None, ssq_out=None, sched=None, tile=None, kind=None):
         if tile is not None:
             rc = self.lib.lgen_gemm_tile(L.ptr(wp), L.ptr(xp), L.ptr(out), M, mts, N, K, epi, self.dt, *tile, L.ptr(norm_w),
                                          L.ptr(self.ssq) if norm_w is not None else 0, self.ssq_parts, self.eps, L.ptr(ssq_out),
@@ -578,6 +613,9 @@ class DecodeEngine:
             if rc != L.ERR_UNSUPPORTED:   # no instantiation / shape does not divide: the skinny kernel below
                 L.check(rc, "lgen_gemm_tile")
                 return
+            if kind is not None:          # ... from now on, and gemm_schedule() / tile_schedule_tested() say so
+                self._tile_refused.add(kind)
+                self._graphs = {}
         mt, nt, kw = tiles
         if mts % mt:
             mt = math.gcd(mts, mt)
@@ -602,6 +640,8 @@ class DecodeEngine:
             if rc != L.ERR_UNSUPPORTED:
                 L.check(rc, "gemm_qkv_rope_tile")
                 return
+            self._tile_refused.add("qkv")
+            self._graphs = {}
         tq = self._tiles("qkv", 3 * d, d)
         sq = self._passes("qkv", 3 * d, tq)
         qkv_fn = lib.lgen_gemm_qkv_rope_rows if rows else lib.lgen_gemm_qkv_rope
@@ -616,17 +656,17 @@ class DecodeEngine:
         fuse = self.fuse_norm
         ssq = self.ssq if fuse else None
         if kind == "wo":
-            self.gemm(w["wo"], self.ap, self.hp, M, mts, d, d, L.EPI_RES, self._tiles("wo", d, d), ssq_out=ssq, tile=self._tile_shape("wo"))
+            self.gemm(w["wo"], self.ap, self.hp, M, mts, d, d, L.EPI_RES, self._tiles("wo", d, d), ssq_out=ssq, tile=self._tile_shape("wo"), kind="wo")
         elif kind == "w13":
             t13 = self._tiles("w13", 2 * F, d)
             self.gemm(w["w13"], x_in if x_in is not None else self.hp, self.gp, M, mts, 2 * F, d, L.EPI_SWIGLU, t13, norm_w=nw,
-                      sched=self._passes("w13", 2 * F, t13), tile=self._tile_shape("w13") if nw is not None else None)
+                      sched=self._passes("w13", 2 * F, t13), tile=self._tile_shape("w13") if nw is not None else None, kind="w13")
         elif kind == "w2":
-            self.gemm(w["w2"], self.gp, self.hp, M, mts, d, F, L.EPI_RES, self._tiles("w2", d, F), ssq_out=ssq, tile=self._tile_shape("w2"))
+            self.gemm(w["w2"], self.gp, self.hp, M, mts, d, F, L.EPI_RES, self._tiles("w2", d, F), ssq_out=ssq, tile=self._tile_shape("w2"), kind="w2")
         elif kind == "head":
             th = self._tiles("head", self.V, d)
             self.gemm(self.out_w, x_in if x_in is not None else self.hp, self.logits, M, mts, self.V, d, L.EPI_ROWS, th, norm_w=nw,
-                      sched=self._passes("head", self.V, th), tile=self._tile_shape("head") if nw is not None else None)
+                      sched=self._passes("head", self.V, th), tile=self._tile_shape("head") if nw is not None else None, kind="head")
         else:
             raise ValueError(kind)
 

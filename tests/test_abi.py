@@ -169,7 +169,7 @@ def test_pinned_tile_schedules_are_shapes_the_library_takes(lib):
     from llamagen_amd import _lib as L
     from llamagen_amd.engine import (DecodeEngine, MODEL_TILE_SCHEDULES, TESTED_MODEL_SCHEDULES, TILE_SCHEDULES, TILE_SCHEDULE_EXACT,
                                      tile_schedule_key)
-    heads = {1024: 16, 1536: 24, 3200: 32}
+    heads = {1024: 16, 1280: 20, 1536: 24, 3200: 32}
     bad = []
     for (d, F, V), table in MODEL_TILE_SCHEDULES.items():
         H, hd = heads[d], d // heads[d]
@@ -194,7 +194,8 @@ def test_pinned_tile_schedules_are_shapes_the_library_takes(lib):
 
     def eng(d, F, V, mts, **kw):
         e = types.SimpleNamespace(d=d, F=F, V=V, MTs=mts, hd=64, dtype=torch.bfloat16, fuse_norm=True, use_tile=True, tile_autotune=False,
-                                  tile_shape_override={}, tile_override={}, pass_override={}, pos_rows=None, mt=4, kc=32, lib=lib)
+                                  tile_shape_override={}, tile_override={}, pass_override={}, pos_rows=None, mt=4, kc=32, lib=lib,
+                                  _tile_refused=set())
         e.__dict__.update(kw)
         for name in ("_tile_shape", "_tiles", "_passes", "gemm_schedule", "tile_schedule_source", "tile_schedule_tested"):
             setattr(e, name, types.MethodType(getattr(DecodeEngine, name), e))
@@ -208,9 +209,16 @@ def test_pinned_tile_schedules_are_shapes_the_library_takes(lib):
     assert xxl._tile_shape("w2") == MODEL_TILE_SCHEDULES[(1536, 4096, 16384)][16]["w2"] and xxl.tile_schedule_tested()
     b3 = eng(3200, 8704, 16384, 16)
     assert b3._tile_shape("qkv") == (8, 1, 1, 6, 2, 4, 4) and b3.tile_schedule_tested()
-    other = eng(1280, 3584, 16384, 16)                                              # GPT-XL: no table of its own -> GPT-L's shapes by width
+    assert eng(1536, 4096, 16384, 32)._tile_shape("qkv") == (8, 1, 1, 6, 2, 4, 4) and eng(1536, 4096, 16384, 32).tile_schedule_tested()   # round 6: 512 rows
+    b3w = eng(3200, 8704, 16384, 32)
+    assert b3w._tile_shape("w2") == (2, 2, 4, 2, 2, 4, 4) and b3w.tile_schedule_tested()
+    xl = eng(1280, 3584, 16384, 16)                                                 # GPT-XL (config 5): its own table since round 6
+    assert xl._tile_shape("qkv") == (4, 1, 1, 4, 4, 4, 4) and xl.tile_schedule_source() == "table" and xl.tile_schedule_tested()
+    other = eng(768, 2048, 16384, 16)                                               # GPT-B: no table of its own -> GPT-L's shapes by width
     assert other._tile_shape("wo") == TILE_SCHEDULES[16]["wo"] and not other.tile_schedule_tested()
     assert other.tile_schedule_source().startswith("table (GPT-L")
+    refused = eng(768, 2048, 16384, 16, _tile_refused={"w2"})                       # a shape the library refused at first launch: reported as skinny
+    assert refused._tile_shape("w2") is None and refused.gemm_schedule()["w2"]["family"] == "skinny"
     assert not eng(1024, 2816, 16384, 40, tile_shape_override={"wo": (2, 2, 1, 1, 4, 4, 4)}).tile_schedule_tested()
     assert set(TESTED_MODEL_SCHEDULES) == set(MODEL_TILE_SCHEDULES)
     # K/V rows packed tighter than the lane group (round 5): head_dim 100 takes rows of 104 elements (bf16) / 100 (fp32), not 96

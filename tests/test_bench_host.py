@@ -120,7 +120,16 @@ def test_config2_schedules_only_tested_chain_widths():
         got[steps] = (bpc, a.lanes)
         assert bpc in (1, 2, 3, 4, 5, 6, 10) and per_chain > 0
     assert got[20] == (10, 2) and got[24] == (10, 2) and got[14] == (6, 2) and got[16] == (6, 2) and got[12] == (6, 2) and got[1] == (1, 1)
-    # KV budget: GPT-3B's rows are 104 elements apart, not 128 (config 4)
+    # KV budget: GPT-3B's rows are 104 elements apart, not 128 (config 4); round 6: two chains of FOUR batches of 64 (512 rows)
     a = argparse.Namespace(config=4, steps=8, batches_per_chain=0, lanes=0, no_one_chain=True)
     bpc, per_chain = bench.plan_schedule(a, 64, 576, 1)
-    assert bpc == 2 and abs(per_chain - (24 * 2 * 64 * 2 * 32 * 585 * 104 * 2 * 2 + 576 * 64 * 2 * 16384 * 4)) < 1e6
+    assert bpc == 4 and a.lanes == 2 and abs(per_chain - (24 * 2 * 64 * 4 * 32 * 585 * 104 * 2 * 2 + 576 * 64 * 4 * 16384 * 4)) < 1e6
+    a = argparse.Namespace(config=4, steps=4, batches_per_chain=0, lanes=0, no_one_chain=True)      # a short run keeps 2 x 2
+    assert bench.plan_schedule(a, 64, 576, 1)[0] == 2 and a.lanes == 2
+    # configs 3 / 5 (round 6): two chains of eight batches; the one-chain transparency leg is dropped when a third chain's slabs do not fit
+    a = argparse.Namespace(config=3, steps=16, batches_per_chain=0, lanes=0, no_one_chain=False)
+    assert bench.plan_schedule(a, 32, 576, 1)[0] == 8 and a.lanes == 2 and a.no_one_chain
+    a = argparse.Namespace(config=3, steps=12, batches_per_chain=0, lanes=0, no_one_chain=False)
+    assert bench.plan_schedule(a, 32, 576, 1)[0] == 6 and a.lanes == 2
+    a = argparse.Namespace(config=5, steps=16, batches_per_chain=0, lanes=0, no_one_chain=True)
+    assert bench.plan_schedule(a, 16, 1024, 120)[0] == 8 and a.lanes == 2

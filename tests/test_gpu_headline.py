@@ -784,6 +784,38 @@ def test_config3_gptxxl_shapes_bf16_vs_oracle(B):
     _check(f"config3_gptxxl_shapes_b{B}", recs)
 
 
+@pytest.mark.parametrize("model", ["XXL", "3B", "XL-t2i"])
+def test_configs_3_4_5_wide_chain_shapes_bf16_vs_oracle(model):
+    """Round 6: the chain widths `bench.py --config 3 / 4 / 5` runs now -- GPT-XXL two chains of eight batches of 32 (512 rows), GPT-3B
+    two chains of four batches of 64 (512 rows), GPT-XL t2i two chains of eight batches of 16 (256 rows, T = 120 caption tokens with
+    left-padded emb_masks) -- on the shapes engine.MODEL_TILE_SCHEDULES pins for that model and width (keys 32 / 32 / 16, measured with
+    tools/gemm_tile_sweep.py).  Depth cut to 2 layers and the token grid to 16 x 16 (block_size 256; the GEMM shapes do not depend on
+    either) so that two CPU oracles of 512 rows stay within ~15 GB and a minute; the 384 / 512 px slab lengths are held by the 128- /
+    192- / 32-row cases above and the full-depth goldens below."""
+    if model == "XL-t2i":
+        kw = dict(n_layer=2, n_head=20, dim=1280, vocab_size=16384, block_size=256, cls_token_num=120, caption_dim=2048, model_type="t2i")
+        B, T, scale, key, late = 128, 120, 7.5, 16, [370]
+        g = torch.Generator().manual_seed(15)
+        emb = torch.randn(B, T, 2048, generator=g)
+        lens = torch.randint(5, T + 1, (B,), generator=g)
+        mask = torch.zeros(B, T, dtype=torch.int64)
+        for b in range(B):
+            mask[b, T - int(lens[b]):] = 1
+        cond = (emb * mask[:, :, None]).to(torch.bfloat16).float()
+    else:
+        H, d = {"XXL": (24, 1536), "3B": (32, 3200)}[model]
+        kw = dict(n_layer=2, n_head=H, dim=d, vocab_size=16384, block_size=256, num_classes=1000, cls_token_num=1, model_type="c2i")
+        B, T, scale, key, late, mask = 256, 1, 4.0, 32, [250], None
+        cond = torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(16))
+    case = dict(kwargs=kw, wseed=26, lin_std=0.02)
+    recs, m = _teacher_forced(case, B, scale, early=2, late=late, cond=cond, emb_masks=mask, T=T)
+    e = m._engine
+    from llamagen_amd.engine import MODEL_TILE_SCHEDULES, tile_schedule_key
+    assert e.MTs == 2 * B // 16 and tile_schedule_key(e.MTs, MODEL_TILE_SCHEDULES[(e.d, e.F, e.V)]) == key
+    _log(f"config_wide_chain_{model}_{2 * B}rows", dict(schedule=str(_pinned_model_schedule(e))))
+    _check(f"config_wide_chain_{model}", recs)
+
+
 @pytest.mark.parametrize("name", ["gptxxl_c3", "gpt3b_c4", "gptxl_t2i_c5"])
 def test_configs_3_4_5_full_depth_vs_reference_golden(name):
     """BASELINE configs 3 / 4 / 5 at FULL depth (GPT-XXL 48 layers, GPT-3B 24 with head_dim 100, GPT-XL t2i 36 with T = 120 and

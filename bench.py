@@ -405,9 +405,9 @@ def cpu_baseline(steps=16, budget_s=30.0, with_c1=True):
         # same-host calibration of the port against the reference's own modules (tools/cpu_calibrate.py, run in the build container
         # where /root/reference exists): how much faster / slower the port is than the reference on the same slice
         try:
-            cal = json.load(open(os.path.join(ROOT, "profiles", "r04_cpu_ref_vs_port.json")))
+            cal = json.load(open(os.path.join(ROOT, "profiles", CPU_CAL_JSON)))
             out["port_over_reference"] = {"slice_images_per_s": cal["port_over_reference"]["slice"], "c1_images_per_s": cal["port_over_reference"]["c1"],
-                                          "source": "profiles/r04_cpu_ref_vs_port.json (both run back to back in the build container, same threads)"}
+                                          "source": f"profiles/{CPU_CAL_JSON} (both run back to back in the build container, same threads)"}
             out["c1"]["port_over_reference"] = cal["port_over_reference"]["c1"]
         except Exception:  # noqa: BLE001
             out["port_over_reference"] = None
@@ -833,6 +833,7 @@ HBM_BUDGET_BYTES = 215e9   # KV slabs + noise of the chains in flight per GPU (2
 MFMA_BF16_PEAK_TFLOPS = 2500.0
 PMC_JSON = "r05_pmc.json"
 SQ_PMC_JSON = "r06_sq_pmc.json"
+CPU_CAL_JSON = "r06_cpu_ref_vs_port.json"   # tools/cpu_calibrate.py, re-run every round in the build container
 
 
 def PMC_POSITIONS(N, T=1):

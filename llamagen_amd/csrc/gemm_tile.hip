@@ -539,8 +539,8 @@ static int gt_dispatch(const GemmArgs& a, int wm, int wn, int mtv, int ntv, int 
 }
 
 static int gt_ablate() {   // development switch: bit 0 no RMSNorm VALU work, bit 1 no LDS reads / MFMAs, bit 2 no operand DMA, bit 3 no epilogue, bit 4 no statistics prologue
-    const char* e = getenv("LGEN_TILE_ABLATE");
-    return (e ? atoi(e) : 0) & 0xff;
+    static const int v = [] { const char* e = getenv("LGEN_TILE_ABLATE"); return (e ? atoi(e) : 0) & 0xff; }();   // read once per process
+    return v;
 }
 
 static int gt_dispatch_epi(const GemmArgs& a, int epi, int wm, int wn, int mtv, int ntv, int kb, int stages, int lw, hipStream_t st) {

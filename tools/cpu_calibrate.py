@@ -1,6 +1,6 @@
 """Same-host calibration of bench.py's CPU leg (round 4): the reference's own modules (/root/reference) and the oracle port, run
 back to back in the build container on the same bounded slice (bench.cpu_baseline: 32-step B = 32 slice + config 1 in full) with
-the same thread count.  Writes profiles/r04_cpu_ref_vs_port.json; bench.py quotes `port_over_reference` next to a `kind: "port"`
+the same thread count.  Writes profiles/r06_cpu_ref_vs_port.json (round 6 re-run; r04_cpu_ref_vs_port.json is the round-4 pass); bench.py quotes `port_over_reference` next to a `kind: "port"`
 figure on boxes without the reference mount.
     python tools/cpu_calibrate.py
 """
@@ -28,7 +28,7 @@ def main():
     assert ref["kind"] == "reference" and port["kind"] == "port", (ref["kind"], port["kind"])
     out = {"host_logical_cores": os.cpu_count(), "reference": ref, "port": port,
            "port_over_reference": {"slice": round(port["value"] / ref["value"], 3), "c1": round(port["c1"]["value"] / ref["c1"]["value"], 3)}}
-    json.dump(out, open(os.path.join(ROOT, "profiles", "r04_cpu_ref_vs_port.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(ROOT, "profiles", "r06_cpu_ref_vs_port.json"), "w"), indent=1)
     print(json.dumps(out["port_over_reference"]), ref["value"], port["value"], ref["c1"], port["c1"])
 
 

@@ -82,7 +82,7 @@ def plan_schedule(args, B, N, T):
     else:
         # GPT-XL t2i: two chains of eight batches of 16 (256 rows: tile family; round 6: 20.0 img/s against 17.8 for three chains of
         # four on the skinny kernels)
-        bpc = 8 if args.steps >= 16 else 4
+        bpc = 12 if args.steps >= 24 else (8 if args.steps >= 16 else 4)   # 2 x 12 (384 rows): 21.0-21.2 against 20.8 for 2 x 8
     chains = (args.steps + bpc - 1) // bpc
     n_layer, n_head, dim = GPT_DIMS[CONFIGS[args.config]["gpt"]]
     kvs = -(-(dim // n_head) // 8) * 8   # elements between key rows: head_dim rounded up to one 16-byte piece (engine.py)
@@ -453,7 +453,7 @@ def other_configs(timeout_s=420):
     untested one before timing).  Returns {"config3": {...}, "config4": {...}, "config5": {...}}; a failed pass is reported as such,
     never invented."""
     out = {}
-    for c, steps, warm in ((3, 16, 4), (4, 8, 2), (5, 16, 4)):
+    for c, steps, warm in ((3, 16, 4), (4, 8, 2), (5, 24, 4)):
         cmd = [sys.executable, os.path.abspath(__file__), "--config", str(c), "--steps", str(steps), "--warmup", str(warm),
                "--no-cpu-baseline", "--no-live-traffic", "--no-solo", "--no-one-chain", "--no-roofline"]
         t0 = time.time()

@@ -12,7 +12,8 @@
  * `lgen_debug_*` section at the end of this header (process-wide ints read at launch time, never set by the product path) and the
  * LGEN_GEMM_STEADY / LGEN_TILE_ABLATE environment variables (read at launch = capture time; bit-identical results / timing
  * ablations).  ABI v8 = v7 + a K/V row stride that may be smaller than the lane group hdp (lgen_gemm_qkv_rope); ABI v9 = v8 minus
- * lgen_conv_wino (the Winograd experiment of round 5 left the product library: tools/experiments/conv_wino/).  Each entry point
+ * lgen_conv_wino (the Winograd experiment of round 5 left the product library: tools/experiments/conv_wino/); ABI v10 = v9 +
+ * lgen_ssq_group4 (row statistics pre-grouped for the fused-norm consumers) and key-row stride checks in the prefill entry points.  Each entry point
  * cites the reference op sequence it replaces (paths relative to the reference repository root).
  *
  * Fragment-packed layouts ("chunk" = 1 KiB = [16 rows][KC k] in MFMA operand order, lane =
@@ -27,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LGEN_ABI_VERSION 9
+#define LGEN_ABI_VERSION 10
 #define LGEN_BF16 0
 #define LGEN_F32 1
 #define LGEN_F16 2   /* fp16 storage: BF16's layouts (KC = 32, EPL = 8), IEEE half rounding, v_mfma_f32_16x16x32_f16 */
@@ -62,6 +63,12 @@ int lgen_embed_pack(const void* table, const int* idx, void* hp, float* ssq_out,
 /* Row sums of squares of an already packed residual stream hp = XP[d/KC][MTs] (t2i prefix rows produced
  * by the CaptionEmbedder MLP): ssq_out [MTs*16][LGEN_SSQ_STRIDE] fp32 (d/16 partials per row), the ssq_in of a fused RMSNorm. */
 int lgen_ssq_pack(const void* hp, float* ssq_out, int MTs, int d, int dtype, void* stream);
+
+/* Round 6 (ABI v10): the four lane-group sums of every statistics row -- ssq_out[row][0..3] = sum of ssq_in[row][q], q = g, g + 4, ...
+ * ascending, g = 0..3 -- i.e. what every fused-norm consumer computes first from a `ssq_parts`-partial row.  A consumer given
+ * ssq_out with ssq_parts = 4 produces the SAME bits as with ssq_in and the original count, and skips the per-workgroup reduction
+ * (GPT-3B, 200 partials: 25-38 us of a 99-140 us launch).  rows = MTs * 16, parts % 4 == 0, ssq_out != ssq_in. */
+int lgen_ssq_group4(const float* ssq_in, float* ssq_out, int rows, int parts, void* stream);
 
 /* RMSNorm.forward (gpt.py:143-148) on XP -> XP, fp32 math, two storage roundings. */
 int lgen_rmsnorm(const void* hp, const void* weight, void* xnp, int MTs, int d, float eps, int dtype, void* stream);

@@ -17,9 +17,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblgen_hip.so")
 BF16, F32, F16 = 0, 1, 2
 EPI_ROWS, EPI_PACKED, EPI_GELU, EPI_RES, EPI_SWIGLU, EPI_QKV = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 9
+ABI_VERSION = 10
 SSQ_STRIDE = 256  # LGEN_SSQ_STRIDE: floats per row of a fused-RMSNorm statistics array
 ERR_UNSUPPORTED = -2
+ERR_BAD_ARG = -1
 
 _c = ctypes
 _P, _I, _F = _c.c_void_p, _c.c_int, _c.c_float
@@ -29,6 +30,7 @@ SIGNATURES = {
     "lgen_abi_version": [],
     "lgen_embed_pack": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "lgen_ssq_pack": [_P, _P, _I, _I, _I, _P],
+    "lgen_ssq_group4": [_P, _P, _I, _I, _P],
     "lgen_rmsnorm": [_P, _P, _P, _I, _I, _F, _I, _P],
     "lgen_gemm": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _F, _P, _I, _P],
     "lgen_gemm_max_kw": [_I, _I, _I, _I],

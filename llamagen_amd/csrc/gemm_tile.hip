@@ -215,16 +215,20 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_tile_kernel(GemmArgs
                 res[j][i] = *(const uint2*)((const uint16_t*)a.out + D::xp_off(nt * 16 + (lane >> 4) * 4, mtw0 + i, lane & 15, a.MTs));
             }
     }
-    if constexpr (EPI == EPI_QKV) {
+    // (wave tiles of >= 20 MFMA tiles -- the 128 x 160 shape of GPT-3B's wqkv -- request the RoPE factors in the epilogue instead,
+    // where the operand fragments are dead: 40 more registers across the K loop spill at 256)
+    constexpr bool ROPE_LATE = EPI == EPI_QKV && MTV * NTV >= 20;
+    auto load_rope = [&]() {
         QkvCol qc;
         qc.init((ntw0 < ntiles ? ntw0 : ntiles - 1) * 16 + (lane >> 4) * 4, a.d, a.hd);
 #pragma unroll
-        for (int j = 0; j < NTV; ++j) {
+        for (int j = 0; j < (EPI == EPI_QKV ? NTV : 1); ++j) {
             rope[j] = make_uint4(0, 0, 0, 0);
             if (qc.sec < 2) rope[j] = *(const uint4*)(a.freqs + ((size_t)pos * (a.hd >> 1) + (qc.dd >> 1)) * 2);
             qc.next16(a.hd, a.H);
         }
-    }
+    };
+    if constexpr (EPI == EPI_QKV && !ROPE_LATE) load_rope();
 
     // ---- DMA bookkeeping (LW == 0 only): piece p of this wave is chunk c = w + p * NL of a stage ----
     const uint4* src[LW == 0 ? P : 1];
@@ -391,6 +395,7 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_tile_kernel(GemmArgs
     if (a.db & 8) return;   // ablation: no epilogue
     // ---- epilogue: this wave's NTV x MTV tiles ----
     if constexpr (EPI == EPI_QKV) {
+        if constexpr (ROPE_LATE) load_rope();
         QkvCol qc;
         qc.init((ntw0 < ntiles ? ntw0 : ntiles - 1) * 16 + (lane >> 4) * 4, a.d, a.hd);
         const int r = lane & 15;
@@ -516,7 +521,7 @@ static int gt_launch(const GemmArgs& a_in, hipStream_t st) {
 #define GT_SHAPES_NORM(X)                                                                                        \
     X(4, 1, 1, 3, 4, 4, 4) X(4, 1, 1, 4, 4, 4, 4) X(4, 1, 1, 6, 2, 4, 4) X(4, 1, 1, 6, 4, 3, 4) X(4, 1, 1, 8, 2, 4, 4) \
     X(4, 1, 2, 4, 2, 4, 4) X(4, 1, 2, 6, 2, 4, 4) X(4, 1, 2, 8, 2, 4, 4) X(4, 1, 1, 2, 4, 4, 4) X(4, 1, 1, 3, 4, 4, 0) \
-    X(8, 1, 1, 8, 2, 4, 4) X(8, 1, 1, 6, 2, 4, 4) X(8, 1, 1, 4, 2, 4, 4)
+    X(8, 1, 1, 8, 2, 4, 4) X(8, 1, 1, 6, 2, 4, 4) X(8, 1, 1, 4, 2, 4, 4) X(4, 1, 2, 10, 2, 4, 4)
 #define GT_SHAPES_PLAIN(X)                                                                                       \
     X(2, 2, 1, 1, 4, 4, 4) X(2, 2, 1, 2, 4, 4, 4) X(2, 2, 2, 1, 4, 4, 4) X(2, 2, 2, 2, 4, 4, 4) X(2, 2, 2, 2, 2, 4, 4) \
     X(4, 1, 1, 2, 4, 4, 4) X(2, 2, 1, 1, 4, 4, 0) X(2, 2, 4, 1, 4, 4, 4) X(2, 2, 4, 2, 2, 4, 4)

@@ -378,6 +378,38 @@ __global__ __launch_bounds__(64 * ATT_NW * HPW, (ATT_CH <= 2 ? 4 : 2)) void attn
     }
 }
 
+// Round 6: the 4 lane-group sums of a statistics row, computed ONCE per row instead of once per consumer workgroup.  A fused-norm
+// consumer (gemm_tile.hip prologue, ssq_rows_now) sums a row's `parts` partials as 4 lane-group sums s_g = sum of the partials q = g,
+// g + 4, g + 8, ... in ascending order, then (s_0 + s_1) + (s_2 + s_3) by two cross-lane adds.  For `parts` that are not a multiple
+// of 16 (GPT-3B: d / 16 = 200) that loop is 50 dependent-batch loads per wave, repeated by every one of the 400-728 workgroups of a
+// launch: 25 of the 99 us of GPT-3B's wqkv at 512 rows and 38 of the 140 us of w1||w3 (profiles/r06_tile_ablations_3b.log, mask 16).
+// This kernel writes s_0 .. s_3 as a 4-partial row; a consumer given parts = 4 then reads s_g alone (0.f + s_g = s_g) and finishes
+// with the same two cross-lane adds: the SAME bits, whatever `parts` was.  One thread per row, the row's float4s loaded in
+// batches of 32 (independent loads), added component-wise in ascending order (component g of float4 k is partial 4k + g).
+__global__ __launch_bounds__(64) void ssq_group4_kernel(const float* __restrict__ ssq_in, float* __restrict__ ssq_out, int rows, int parts) {
+    const int row = blockIdx.x * 64 + threadIdx.x;
+    if (row >= rows) return;
+    const float4* p = (const float4*)(ssq_in + (size_t)row * LGEN_SSQ_STRIDE);
+    const int n4 = parts >> 2;   // launcher: parts % 4 == 0
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int k0 = 0; k0 < n4; k0 += 32) {   // <= 2 round trips per row (parts <= 256)
+        float4 v[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) v[j] = p[k0 + j < n4 ? k0 + j : n4 - 1];
+#pragma unroll
+        for (int j = 0; j < 32; ++j)
+            if (k0 + j < n4) { s0 += v[j].x; s1 += v[j].y; s2 += v[j].z; s3 += v[j].w; }
+    }
+    *(float4*)(ssq_out + (size_t)row * LGEN_SSQ_STRIDE) = make_float4(s0, s1, s2, s3);
+}
+
+extern "C" int lgen_ssq_group4(const float* ssq_in, float* ssq_out, int rows, int parts, void* stream) {
+    if (!ssq_in || !ssq_out || ssq_in == ssq_out || rows < 1 || parts < 4 || parts % 4 || parts > LGEN_SSQ_STRIDE) return LGEN_ERR_BAD_ARG;
+    hipLaunchKernelGGL(ssq_group4_kernel, dim3((rows + 63) / 64), dim3(64), 0, (hipStream_t)stream, ssq_in, ssq_out, rows, parts);
+    LGEN_CHECK_LAUNCH();
+    return 0;
+}
+
 // ---- persistent form (round 4, variant 8) ---------------------------------------------------------------------------------
 // Same arithmetic per (batch row, head) as attn_decode_kernel with one wave per item (the wave-level online softmax of variants
 // 4 / 5: every group of CH x KPL keys updates one wave-uniform running maximum, so the result does not depend on how many waves

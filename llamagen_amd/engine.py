@@ -136,7 +136,7 @@ def tile_schedule_key(mts: int, table=None):
 # the family, so it only ever changes the speed.
 TILE_SHAPES_NORM = ((4, 1, 1, 3, 4, 4, 4), (4, 1, 1, 4, 4, 4, 4), (4, 1, 1, 6, 2, 4, 4), (4, 1, 1, 6, 4, 3, 4), (4, 1, 1, 8, 2, 4, 4),
                     (4, 1, 2, 4, 2, 4, 4), (4, 1, 2, 6, 2, 4, 4), (4, 1, 2, 8, 2, 4, 4), (4, 1, 1, 2, 4, 4, 4), (8, 1, 1, 8, 2, 4, 4),
-                    (8, 1, 1, 6, 2, 4, 4), (8, 1, 1, 4, 2, 4, 4))
+                    (8, 1, 1, 6, 2, 4, 4), (8, 1, 1, 4, 2, 4, 4), (4, 1, 2, 10, 2, 4, 4))
 TILE_SHAPES_PLAIN = ((2, 2, 1, 1, 4, 4, 4), (2, 2, 1, 2, 4, 4, 4), (2, 2, 2, 1, 4, 4, 4), (2, 2, 2, 2, 4, 4, 4), (2, 2, 2, 2, 2, 4, 4),
                      (4, 1, 1, 2, 4, 4, 4), (2, 2, 4, 1, 4, 4, 4), (2, 2, 4, 2, 2, 4, 4))
 _TUNED = {}   # (device index, dim, F, V, n_head, MTs, per-row positions?) -> {kind: shape | None}: one search per process, shared by every lane
@@ -253,6 +253,10 @@ class DecodeEngine:
             raise ValueError(f"dim {self.d} exceeds the fused-RMSNorm statistics row ({L.SSQ_STRIDE} x 16 columns)")
         self.ssq = z(mts * 16, L.SSQ_STRIDE, dtype=torch.float32)  # per row: d/16 partial sums of squares (fused RMSNorm)
         self.ssq_parts = 0
+        # round 6: rows of `parts` partials that the consumers' fast path does not take (parts % 16 != 0 or > 128 -- GPT-3B: 200) are
+        # grouped ONCE per consumer launch into their 4 lane-group sums (lgen_ssq_group4 -> ssq_g, parts 4: the same bits) instead
+        # of once per consumer workgroup (profiles/r06_tile_ablations_3b.log: 25-38 us of a 99-140 us launch)
+        self.ssq_g = z(mts * 16, L.SSQ_STRIDE, dtype=torch.float32)
         self.noise = None            # [N][B][V] fp32 Exp(1) draws of one generate() (allocated on demand)
         self.cur_tok = z(mts * 16, dtype=torch.int32)
         self.seq = z(max_batch, S8 + 8, dtype=torch.int32)
@@ -605,11 +609,20 @@ class DecodeEngine:
         return passes, 0
 
     # ---- launches -----------------------------------------------------------------------------
+    def _grouped_stats(self):
+        """(statistics buffer, partials per row) for a fused-norm consumer of the TILE family: the producer's rows as they are where
+        the consumers' fast path takes them, else their 4 lane-group sums, computed here by one small launch (bit-identical)."""
+        parts = self.ssq_parts
+        if parts % 16 == 0 and parts <= 128 or parts % 4 or parts <= 4:
+            return self.ssq, parts
+        L.check(self.lib.lgen_ssq_group4(L.ptr(self.ssq), L.ptr(self.ssq_g), self.MTs * 16, parts, L.stream()), "ssq_group4")
+        return self.ssq_g, 4
+
     def gemm(self, wp, xp, out, M, mts, N, K, epi, tiles, norm_w=None, ssq_out=None, sched=None, tile=None, kind=None):
         if tile is not None:
+            sq, parts = self._grouped_stats() if norm_w is not None else (None, self.ssq_parts)
             rc = self.lib.lgen_gemm_tile(L.ptr(wp), L.ptr(xp), L.ptr(out), M, mts, N, K, epi, self.dt, *tile, L.ptr(norm_w),
-                                         L.ptr(self.ssq) if norm_w is not None else 0, self.ssq_parts, self.eps, L.ptr(ssq_out),
-                                         L.stream())
+                                         L.ptr(sq), parts, self.eps, L.ptr(ssq_out), L.stream())
             if rc != L.ERR_UNSUPPORTED:   # no instantiation / shape does not divide: the skinny kernel below
                 L.check(rc, "lgen_gemm_tile")
                 return
@@ -634,9 +647,10 @@ class DecodeEngine:
         ssq = self.ssq if nw is not None else None
         bq = self._tile_shape("qkv")
         if bq is not None and nw is not None and not rows:
+            sq, parts = self._grouped_stats()
             rc = lib.lgen_gemm_qkv_rope_tile(L.ptr(w["wqkv"]), L.ptr(x_in), L.ptr(self.qbuf), L.ptr(self.k_cache[i]),
                                              L.ptr(self.v_cache[i]), L.ptr(self.freqs_cis), pos_ptr, M, mts, d, H, hd, hdp, S8,
-                                             self.kvs, dt, *bq, L.ptr(nw), L.ptr(ssq), self.ssq_parts, self.eps, st)
+                                             self.kvs, dt, *bq, L.ptr(nw), L.ptr(sq), parts, self.eps, st)
             if rc != L.ERR_UNSUPPORTED:
                 L.check(rc, "gemm_qkv_rope_tile")
                 return
@@ -760,7 +774,10 @@ class DecodeEngine:
     def launches_per_step(self) -> int:
         """Kernel launches of one captured decode step (embed + L layers + norm/lm_head + sampler)."""
         per_layer = 5 if self.fuse_norm else 7
-        return 1 + len(self.layers) * per_layer + (1 if self.fuse_norm else 2) + 1
+        parts = self.d // 16
+        grouped = self.fuse_norm and self._tile_shape("w13") is not None and not (parts % 16 == 0 and parts <= 128 or parts % 4)
+        extra = 2 * len(self.layers) + 1 if grouped else 0   # lgen_ssq_group4 in front of wqkv, w1||w3 and lm_head (GPT-3B)
+        return 1 + len(self.layers) * per_layer + (1 if self.fuse_norm else 2) + 1 + extra
 
     def _mask(self):
         if self._force_causal:

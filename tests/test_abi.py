@@ -32,7 +32,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/ but not exported"
         assert s in _lib.SIGNATURES, f"{s} has no ctypes signature"
-    assert lib.lgen_abi_version() == _lib.ABI_VERSION == 9
+    assert lib.lgen_abi_version() == _lib.ABI_VERSION == 10
 
 
 def test_header_arg_counts_match_ctypes_signatures():

@@ -133,3 +133,5 @@ def test_config2_schedules_only_tested_chain_widths():
     assert bench.plan_schedule(a, 32, 576, 1)[0] == 6 and a.lanes == 2
     a = argparse.Namespace(config=5, steps=16, batches_per_chain=0, lanes=0, no_one_chain=True)
     assert bench.plan_schedule(a, 16, 1024, 120)[0] == 8 and a.lanes == 2
+    a = argparse.Namespace(config=5, steps=24, batches_per_chain=0, lanes=0, no_one_chain=True)      # what other_configs() runs: 2 x 12 = 384 rows
+    assert bench.plan_schedule(a, 16, 1024, 120)[0] == 12 and a.lanes == 2

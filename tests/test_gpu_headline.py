@@ -508,7 +508,7 @@ def test_fused_norm_gemm_passes_bit_identical(M):
 
 TILE_NORM = [(4, 1, 1, 3, 4, 4, 4), (4, 1, 1, 6, 4, 3, 4), (4, 1, 2, 8, 2, 4, 4), (4, 1, 1, 4, 4, 4, 4), (4, 1, 1, 6, 2, 4, 4),
              (4, 1, 1, 8, 2, 4, 4), (4, 1, 2, 4, 2, 4, 4), (4, 1, 2, 6, 2, 4, 4), (4, 1, 1, 2, 4, 4, 4), (4, 1, 1, 3, 4, 4, 0),
-             (8, 1, 1, 8, 2, 4, 4), (8, 1, 1, 6, 2, 4, 4), (8, 1, 1, 4, 2, 4, 4)]
+             (8, 1, 1, 8, 2, 4, 4), (8, 1, 1, 6, 2, 4, 4), (8, 1, 1, 4, 2, 4, 4), (4, 1, 2, 10, 2, 4, 4)]
 TILE_PLAIN = [(2, 2, 1, 1, 4, 4, 4), (2, 2, 1, 2, 4, 4, 4), (2, 2, 2, 1, 4, 4, 4), (2, 2, 2, 2, 4, 4, 4), (2, 2, 2, 2, 2, 4, 4),
               (4, 1, 1, 2, 4, 4, 4), (2, 2, 1, 1, 4, 4, 0), (2, 2, 4, 1, 4, 4, 4), (2, 2, 4, 2, 2, 4, 4)]
 
@@ -549,21 +549,21 @@ def test_tile_gemm_family_vs_oracle_and_bit_identical_across_shapes(M, width):
     L.check(lib.lgen_ssq_pack(L.ptr(xp), L.ptr(ssq), mts, d, L.BF16, L.stream()), "ssq_pack")
     state = torch.tensor([pos, 0], dtype=torch.int32, device=dev)
 
-    def run_norm(s):
+    def run_norm(s, ssq=ssq, parts=d // 16):
         kc = torch.zeros(M, H, S8, hdp, dtype=dt, device=dev)
         vc = torch.zeros(M, H, S8, hdp, dtype=dt, device=dev)
         q = torch.zeros(mts * 16, H, hdp, dtype=dt, device=dev)
         gp = torch.zeros(F // 32, mts, 64, 8, dtype=dt, device=dev)
         rows = torch.zeros(mts * 16, V, dtype=dt, device=dev)
         rcs = [lib.lgen_gemm_qkv_rope_tile(L.ptr(wqp), L.ptr(xp), L.ptr(q), L.ptr(kc), L.ptr(vc), L.ptr(fr_d), L.ptr(state), M, mts, d,
-                                           H, hd, hdp, S8, 0, L.BF16, *s, L.ptr(nw_d), L.ptr(ssq), d // 16, 1e-5, L.stream())]
+                                           H, hd, hdp, S8, 0, L.BF16, *s, L.ptr(nw_d), L.ptr(ssq), parts, 1e-5, L.stream())]
         if s[3] % 2 == 0:
             rcs.append(lib.lgen_gemm_tile(L.ptr(w13), L.ptr(xp), L.ptr(gp), M, mts, 2 * F, d, L.EPI_SWIGLU, L.BF16, *s, L.ptr(nw_d),
-                                          L.ptr(ssq), d // 16, 1e-5, 0, L.stream()))
+                                          L.ptr(ssq), parts, 1e-5, 0, L.stream()))
         else:
             gp = None
         rcs.append(lib.lgen_gemm_tile(L.ptr(whp), L.ptr(xp), L.ptr(rows), M, mts, V, d, L.EPI_ROWS, L.BF16, *s, L.ptr(nw_d),
-                                      L.ptr(ssq), d // 16, 1e-5, 0, L.stream()))
+                                      L.ptr(ssq), parts, 1e-5, 0, L.stream()))
         torch.cuda.synchronize()
         if any(rc == L.ERR_UNSUPPORTED for rc in rcs):
             return None
@@ -632,6 +632,22 @@ def test_tile_gemm_family_vs_oracle_and_bit_identical_across_shapes(M, width):
                 _close(unpack_act(got["swiglu"], M), ref_gp, dt, f"norm+swiglu {s}", frac_ulp1=0.08, ulps=3)
             assert torch.equal(first[name], got[name]), (s, name, (first[name].float() - got[name].float()).abs().max().item())
     assert nrun >= 4 and first["swiglu"] is not None, nrun
+    # round 6: the statistics rows grouped ONCE into their four lane-group sums (lgen_ssq_group4; parts = 4 for the consumer) give the
+    # SAME bits as the d / 16 partials -- every width, including GPT-3B's 200 partials, the case the engine groups
+    ssq_g = torch.full((mts * 16, L.SSQ_STRIDE), float("nan"), device=dev)
+    L.check(lib.lgen_ssq_group4(L.ptr(ssq), L.ptr(ssq_g), mts * 16, d // 16, L.stream()), "ssq_group4")
+    assert lib.lgen_ssq_group4(L.ptr(ssq), L.ptr(ssq), mts * 16, d // 16, L.stream()) == L.ERR_BAD_ARG      # in place is refused
+    assert lib.lgen_ssq_group4(L.ptr(ssq), L.ptr(ssq_g), mts * 16, 6, L.stream()) == L.ERR_BAD_ARG           # parts % 4
+    ngrp = 0
+    for s in TILE_NORM:
+        got = run_norm(s, ssq_g, 4)
+        if got is None:
+            continue
+        ngrp += 1
+        for name in ("q", "k", "v", "logits", "swiglu"):
+            if got[name] is not None:
+                assert torch.equal(first[name], got[name]), ("grouped statistics", s, name)
+    assert ngrp >= 4, ngrp
 
     firstp, nrun = None, 0
     for s in TILE_PLAIN:

@@ -48,7 +48,7 @@ def ulp_diff(a, b):
 
 NORM_SHAPES = [(4, 1, 1, 3, 4, 4, 4), (4, 1, 1, 4, 4, 4, 4), (4, 1, 1, 6, 2, 4, 4), (4, 1, 1, 6, 4, 3, 4), (4, 1, 1, 8, 2, 4, 4),
                (4, 1, 2, 4, 2, 4, 4), (4, 1, 2, 6, 2, 4, 4), (4, 1, 2, 8, 2, 4, 4), (4, 1, 1, 2, 4, 4, 4), (4, 1, 1, 3, 4, 4, 0),
-               (8, 1, 1, 8, 2, 4, 4), (8, 1, 1, 6, 2, 4, 4), (8, 1, 1, 4, 2, 4, 4)]
+               (8, 1, 1, 8, 2, 4, 4), (8, 1, 1, 6, 2, 4, 4), (8, 1, 1, 4, 2, 4, 4), (4, 1, 2, 10, 2, 4, 4)]
 PLAIN_SHAPES = [(2, 2, 1, 1, 4, 4, 4), (2, 2, 1, 2, 4, 4, 4), (2, 2, 2, 1, 4, 4, 4), (2, 2, 2, 2, 4, 4, 4), (2, 2, 2, 2, 2, 4, 4),
                 (4, 1, 1, 2, 4, 4, 4), (2, 2, 1, 1, 4, 4, 0), (2, 2, 4, 1, 4, 4, 4), (2, 2, 4, 2, 2, 4, 4)]
 
@@ -70,6 +70,13 @@ def sweep(m, rows, out):
     L.check(lib.lgen_ssq_pack(L.ptr(e.hp), L.ptr(e.ssq), mts, d, dt, L.stream()), "ssq_pack")
     ssq0 = e.ssq.clone()
     e.ssq_parts = d // 16
+    # the tile family's consumers get the rows the engine gives them: grouped once (lgen_ssq_group4, round 6) where d / 16 is not a
+    # multiple of 16 (GPT-3B), else as they are; SWEEP_GROUP4=0 times the un-grouped rows
+    ssq_t, parts_t = ssq0, e.ssq_parts
+    if (parts_t % 16 or parts_t > 128) and os.environ.get("SWEEP_GROUP4", "1") != "0":
+        ssq_t = torch.zeros_like(ssq0)
+        L.check(lib.lgen_ssq_group4(L.ptr(ssq0), L.ptr(ssq_t), mts * 16, parts_t, L.stream()), "ssq_group4")
+        parts_t = 4
     e.state.zero_()
     e.state[0] = 7
     nl = len(e.layers)
@@ -83,11 +90,11 @@ def sweep(m, rows, out):
     def qkv_tile(w, s):
         return lib.lgen_gemm_qkv_rope_tile(L.ptr(w["wqkv"]), L.ptr(e.hp), L.ptr(e.qbuf), L.ptr(e.k_cache[0]), L.ptr(e.v_cache[0]),
                                            L.ptr(e.freqs_cis), L.ptr(e.state), M, mts, d, H, hd, hdp, S8, e.kvs, dt, *s,
-                                           L.ptr(w["an"]), L.ptr(ssq0), e.ssq_parts, e.eps, L.stream())
+                                           L.ptr(w["an"]), L.ptr(ssq_t), parts_t, e.eps, L.stream())
 
     def gemm_tile(wp, xp, o, Nn, K, epi, s, nw=None, ssq_out=None):
         return lib.lgen_gemm_tile(L.ptr(wp), L.ptr(xp), L.ptr(o), M, mts, Nn, K, epi, dt, *s, L.ptr(nw),
-                                  L.ptr(ssq0) if nw is not None else 0, e.ssq_parts, e.eps, L.ptr(ssq_out), L.stream())
+                                  L.ptr(ssq_t) if nw is not None else 0, parts_t, e.eps, L.ptr(ssq_out), L.stream())
 
     # kind -> (skinny(w, tiles, sched), tile(w, shape) -> rc, outputs(), reset(), weights list, shapes, N, K)
     def outs_qkv():

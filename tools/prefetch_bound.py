@@ -80,8 +80,8 @@ def main():
     t_cold, t_hot, t_att = timed(G_cold), timed(G_hot), timed(A)
     # (c) a prefetcher's traffic beside the cold chain: a second stream copies ~27 MB per layer-time (one step = 650 MB per t_cold)
     side = torch.cuda.Stream()
-    src = torch.empty(650 * 1024 * 1024 // 2, dtype=torch.bfloat16, device=dev).normal_()
     dst = torch.empty(8 * 1024 * 1024, dtype=torch.bfloat16, device=dev)
+    src = torch.empty(40 * dst.numel(), dtype=torch.bfloat16, device=dev).normal_()   # 671 MB: one decode step's weight stream
     chunks = src.view(-1, dst.numel())
 
     def background():

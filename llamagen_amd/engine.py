@@ -107,7 +107,11 @@ MODEL_TILE_SCHEDULES = {
     (3200, 8704, 16384): {   # GPT-3B (config 4)
         16: {"qkv": (8, 1, 1, 6, 2, 4, 4), "wo": (2, 2, 2, 2, 4, 4, 4), "w13": (4, 1, 1, 6, 2, 4, 4), "w2": (2, 2, 2, 2, 4, 4, 4),
              "head": (8, 1, 1, 8, 2, 4, 4)},
-        32: {"qkv": (8, 1, 1, 6, 2, 4, 4), "wo": (2, 2, 4, 2, 2, 4, 4), "w13": (4, 1, 2, 6, 2, 4, 4), "w2": (2, 2, 4, 2, 2, 4, 4),
+        # 512 rows, statistics grouped (lgen_ssq_group4): wqkv 128 x 160 tiles = 240 workgroups, ONE round of the 256 CUs, 53.3 us
+        # (75.3 with 128 x 96 = 400 workgroups = two rounds; 98.9 before the grouping: profiles/r06_tile_sweep2_3b.log).  w1||w3 keeps
+        # 128 x 96: the 128 x 160 shape is faster alone (90.1 against 102.9 us) and SLOWER in the two-chain bench -- same box,
+        # alternating (profiles/r06_c4_shape_ab.log): both new 31.4 / 31.4, both old 36.0 / 35.8, new wqkv only 37.2, new w1||w3 only 31.3 img/s
+        32: {"qkv": (4, 1, 2, 10, 2, 4, 4), "wo": (2, 2, 4, 2, 2, 4, 4), "w13": (4, 1, 2, 6, 2, 4, 4), "w2": (2, 2, 4, 2, 2, 4, 4),
              "head": (4, 1, 2, 8, 2, 4, 4)}},
     (1280, 3584, 16384): {   # GPT-XL (config 5, t2i)
         16: {"qkv": (4, 1, 1, 4, 4, 4, 4), "wo": (2, 2, 2, 1, 4, 4, 4), "w13": (4, 1, 1, 8, 2, 4, 4), "w2": (2, 2, 2, 1, 4, 4, 4),

@@ -131,6 +131,8 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_tile_kernel(GemmArgs
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool consumer = LW == 0 || w < NC, loader = LW == 0 || w >= NC;
+    // (round 6, measured and dropped: `s_setprio 2` for all waves / `s_setprio 3` for the loader waves of this kernel, like `s_setprio 3` in the
+    // persistent attention kernel before it: 124.5-125.7 / 124.6 against 124.9-125.4 img/s in the two-chain bench, profiles/r06_c2_bench_ab.log)
     const int lw = LW ? w - NC : w;     // index among the DMA-issuing waves
     const int cw = w < NC ? w : 0;      // index among the consumers
     const int wm = cw / WN, wn = cw - wm * WN;

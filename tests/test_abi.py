@@ -209,7 +209,7 @@ def test_pinned_tile_schedules_are_shapes_the_library_takes(lib):
     assert xxl._tile_shape("w2") == MODEL_TILE_SCHEDULES[(1536, 4096, 16384)][16]["w2"] and xxl.tile_schedule_tested()
     b3 = eng(3200, 8704, 16384, 16)
     assert b3._tile_shape("qkv") == (8, 1, 1, 6, 2, 4, 4) and b3.tile_schedule_tested()
-    assert eng(1536, 4096, 16384, 32)._tile_shape("qkv") == (8, 1, 1, 6, 2, 4, 4) and eng(1536, 4096, 16384, 32).tile_schedule_tested()   # round 6: 512 rows
+    assert eng(1536, 4096, 16384, 32)._tile_shape("qkv") == (4, 1, 2, 6, 2, 4, 4) and eng(1536, 4096, 16384, 32).tile_schedule_tested()   # round 6: 512 rows
     b3w = eng(3200, 8704, 16384, 32)
     assert b3w._tile_shape("w2") == (2, 2, 4, 2, 2, 4, 4) and b3w._tile_shape("qkv") == (4, 1, 2, 10, 2, 4, 4) and b3w.tile_schedule_tested()
     xl = eng(1280, 3584, 16384, 16)                                                 # GPT-XL (config 5): its own table since round 6

@@ -801,6 +801,7 @@ def main():
                 res["roofline"]["traffic_source"] = ("live: rocprofv3 --kernel-trace --pmc FETCH_SIZE, then (separate pass) --pmc WRITE_SIZE, on "
                                                      "tools/pmc_attn_target.py in this bench run (FETCH x 2 gfx950 correction)")
                 res["roofline"]["fetch_over_algorithmic"] = round(ratio, 4)
+        solo = None
         if solo_needed:
             # ... and with ONE generate() + decode_code() of one batch in flight at a time (no cross-batch sharing at all): a fresh
             # single-lane pipeline, set up and timed after everything above
@@ -817,10 +818,15 @@ def main():
         if world == 1 and args.config == 2 and not args.no_other_configs and not args.no_roofline:
             # BASELINE configs 4 and 5 (GPT-3B 384 px batch 64; GPT-XL t2i 512 px batch 16) in the SAME driver run: one short pass
             # each in a fresh process (own models, own HBM), after this process has released its decode state
-            pipe = None
+            import gc
+            pipe = solo = None
             gpt._engine = None
+            gc.collect()
             torch.cuda.empty_cache()
+            free_b, total_b = torch.cuda.mem_get_info()   # the children plan up to 211 GB of KV slabs + noise (config 4): what this process still holds counts
             res["other_configs"] = other_configs()
+            res["other_configs"]["hbm_free_GB_when_started"] = round(free_b / 1e9, 1)
+            res["other_configs"]["hbm_total_GB"] = round(total_b / 1e9, 1)
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only (the other ranks would idle in the barrier)
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)

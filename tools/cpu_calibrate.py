@@ -26,10 +26,21 @@ def main():
     assert os.path.isdir("/root/reference"), "the calibration needs the reference mount (build container)"
     ref, port = leg(False), leg(True)
     assert ref["kind"] == "reference" and port["kind"] == "port", (ref["kind"], port["kind"])
-    out = {"host_logical_cores": os.cpu_count(), "reference": ref, "port": port,
-           "port_over_reference": {"slice": round(port["value"] / ref["value"], 3), "c1": round(port["c1"]["value"] / ref["c1"]["value"], 3)}}
-    json.dump(out, open(os.path.join(ROOT, "profiles", "r06_cpu_ref_vs_port.json"), "w"), indent=1)
-    print(json.dumps(out["port_over_reference"]), ref["value"], port["value"], ref["c1"], port["c1"])
+    path = os.path.join(ROOT, "profiles", "r06_cpu_ref_vs_port.json")
+    this = {"slice": round(port["value"] / ref["value"], 3), "c1": round(port["c1"]["value"] / ref["c1"]["value"], 3),
+            "reference_slice_images_per_s": ref["value"], "port_slice_images_per_s": port["value"],
+            "reference_c1": ref["c1"]["value"], "port_c1": port["c1"]["value"]}
+    passes = []
+    try:   # the build container's host is shared: every pass is kept and the MEDIAN of the ratios is what bench.py quotes
+        passes = json.load(open(path)).get("passes", [])
+    except Exception:  # noqa: BLE001
+        pass
+    passes.append(this)
+    med = lambda k: sorted(p[k] for p in passes)[len(passes) // 2]
+    out = {"host_logical_cores": os.cpu_count(), "reference": ref, "port": port, "passes": passes,
+           "port_over_reference": {"slice": med("slice"), "c1": med("c1"), "statistic": f"median of {len(passes)} passes"}}
+    json.dump(out, open(path, "w"), indent=1)
+    print(json.dumps(out["port_over_reference"]), this)
 
 
 if __name__ == "__main__":

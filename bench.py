@@ -696,7 +696,7 @@ def main():
         res["gpt_phase_floor_ms_per_step_at_8TBps"] = round(total_b / 8e12 * 1e3, 1)
         pmc = {}
         try:  # PMC passes of THIS round (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs; tools/pmc_summary.py)
-            pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_JSON)))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_JSON if os.path.exists(os.path.join(ROOT, "profiles", PMC_JSON)) else "r05_pmc.json")))
         except Exception:  # noqa: BLE001
             pass
         if not args.no_roofline:
@@ -837,7 +837,7 @@ def main():
 
 HBM_BUDGET_BYTES = 215e9   # KV slabs + noise of the chains in flight per GPU (288 GB HBM3E minus weights <= 6.2 GB, decoder activations <= 10 GB at 64 x 384 px, workspaces, slack); round 6: 180 -> 215 for two 512-row chains of GPT-XXL (196 GB) / GPT-3B (211 GB)
 MFMA_BF16_PEAK_TFLOPS = 2500.0
-PMC_JSON = "r05_pmc.json"
+PMC_JSON = "r06_pmc.json"
 SQ_PMC_JSON = "r06_sq_pmc.json"
 CPU_CAL_JSON = "r06_cpu_ref_vs_port.json"   # tools/cpu_calibrate.py, re-run every round in the build container
 

@@ -1,12 +1,12 @@
 """rocprofv3 counter_collection.csv (FETCH_SIZE pass, WRITE_SIZE pass of tools/pmc_target.py) -> profiles/<TAG>_pmc.json and a
-readable profiles/<TAG>_pmc.csv (TAG = LGEN_PMC_TAG, default r05).  FETCH_SIZE is in KB and counts HALF of a wide coalesced read stream on gfx950
+readable profiles/<TAG>_pmc.csv (TAG = LGEN_PMC_TAG, default r06).  FETCH_SIZE is in KB and counts HALF of a wide coalesced read stream on gfx950
 (MI355X_MICROARCH.md, HBM section): bytes = KB * 1024 * 2; WRITE_SIZE: bytes = KB * 1024."""
 import csv, glob, json, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 d, H, hd, F, V = 1024, 16, 64, 2816, 16384
 B2 = 2 * int(os.environ.get("LGEN_PMC_B", "320"))  # rows of the decode chain (tools/pmc_target.py)
-TAG = os.environ.get("LGEN_PMC_TAG", "r05")
+TAG = os.environ.get("LGEN_PMC_TAG", "r06")
 POS = (50, 300, 575)   # tools/pmc_target.py
 XROW = B2 * d * 2   # bytes of one [rows, d] bf16 panel: the activation operand of a GEMM (and the residual a RES epilogue reads)
 GEMM = {  # kernel-name fragment -> (bench key, algorithmic weight bytes)

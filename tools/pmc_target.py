@@ -3,7 +3,7 @@ pass, `--pmc WRITE_SIZE`): (1) a short GPT-L bf16 cfg-4 generate() of LGEN_PMC_B
 per chain, 640 rows; the decode-chain GEMM kernels with the bench's tile shapes; 40 tokens keep the serialized,
 counter-instrumented run short), (2) the decode attention at cache positions
 50 / 300 / 575 on full-size KV slabs, one launch per layer.  tools/pmc_summary.py turns the two outputs into
-profiles/r05_pmc.json, which bench.py quotes as `traffic`."""
+profiles/r06_pmc.json (LGEN_PMC_TAG), which bench.py quotes as `traffic`."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -275,7 +275,7 @@ int lgen_to_uint8_hwc(const float* in_nchw, unsigned char* out_nhwc, int B, int 
  * default is the measured-best choice; kept for A/B measurements and for the parity tests that hold both forms to the oracle) ---- */
 int lgen_debug_set_vq_nt(int v);              /* VQ decoder: non-temporal fp32 activation stores / GroupNorm-pass loads (default 0 = off) */
 int lgen_debug_set_prefill_mfma(int v);       /* lgen_attn_prefill, bf16: 1 (default) MFMA flash kernel; 0 the VALU kernels (always used for fp32) */
-int lgen_debug_set_conv_fused_variant(int v); /* lgen_conv_fused weight tiles: 1 (default) global -> LDS DMA; 0 through staging registers */
+int lgen_debug_set_conv_fused_variant(int v); /* lgen_conv_fused weight tiles: 3 (default since round 6) / 2: global -> LDS DMA + pipelined fragment reads in the 3x3, 128-channel-tile kernel (both / the hi pixel planes of the next tap requested under the current tap's MFMAs); 1 DMA, all fragment reads in front of a tap's MFMAs (rounds 3-5); 0 through staging registers -- every variant gives the same bits */
 int lgen_debug_set_igemm_variant(int v);      /* 3 (default): 128x128 tile, 2 staging sets for pixels / 1 for weights; 0: 1 set; 2: 128x64 tiles; 1 is refused */
 
 #ifdef __cplusplus

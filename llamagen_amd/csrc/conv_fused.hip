@@ -24,6 +24,9 @@
 // LDS: halo tile [plane][k-slice fg][pixel][8 ch] (pixel-major inside a k-slice slab whose size is a
 // multiple of 256 B: the B-operand `ds_read_b128` of 16 consecutive pixels is bank-conflict free for EVERY
 // tap shift), weights in MFMA fragment order (lane-linear, conflict free), double-buffered per tap.
+#include <cstdint>
+#include <type_traits>
+
 #include "lgen_common.h"
 #include "../../include/lgen.h"
 
@@ -54,7 +57,30 @@ LGEN_DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memo
 // DMA = true: the weight tiles go HBM/L2 -> LDS directly (`global_load_lds_dwordx4`, one 1 KiB fragment per wave-instruction; the
 // fragment-packed global layout IS the LDS image), issued right after a step's fragment reads and waited for before the step's
 // closing barrier: no staging registers, no ds_write pass.
-template <int JN, int WNW, int KS, int NWV, bool DMA>
+// PIPE (round 6, with DMA, 3x3 only): the LDS fragment reads of a step no longer all sit in front of its MFMAs.  The pixel fragments of tap
+// t + 1 are requested while tap t's MFMAs run (the halo tile is static for the nine taps of a 32-channel chunk), the weight
+// fragments of a step are waited for pair by pair (counted `lgkmcnt`: LDS operations return in order), so a wave's MFMAs start
+// after two fragment reads instead of sixteen.  The reads are inline asm for the reason gemm_tile.hip gives: behind a
+// `global_load_lds` hipcc drains vmcnt in front of every LDS read it can see.
+template <int OFF>
+LGEN_DEV u32x4_t cf_lds_rd(unsigned addr) {
+    u32x4_t v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+LGEN_DEV void cf_touch(u32x4_t& v) { asm volatile("" : "+v"(v)); }
+LGEN_DEV uint4 cf_u4(const u32x4_t& v) { return make_uint4(v[0], v[1], v[2], v[3]); }
+template <int N>
+LGEN_DEV void cf_wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+template <int I, int N, typename F>
+LGEN_DEV void cf_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        cf_static_for<I + 1, N>(f);
+    }
+}
+
+template <int JN, int WNW, int KS, int NWV, bool DMA, int PIPE = 0>
 __global__ __launch_bounds__(64 * NWV, NWV / 2) void conv_fused_kernel(ConvFArgs a) {
     constexpr int PAD = KS / 2, TH = 8, TW = 16, TAPS = KS * KS, NT = 64 * NWV;  // NT threads, NWV waves (2 workgroups / CU)
     constexpr int WMW = NWV / WNW, JM = TH / WMW;
@@ -245,7 +271,82 @@ __global__ __launch_bounds__(64 * NWV, NWV / 2) void conv_fused_kernel(ConvFArgs
         }
     };
 
-    if constexpr (DMA) {
+    if constexpr (DMA && PIPE != 0) {
+        static_assert(KS == 3 && 2 * (JN - 1) + 2 * JM <= 15, "pipelined form: 3x3 taps; the largest counted wait must fit the 4-bit lgkmcnt");
+        u32x4_t px[2][2 * JM];   // [step parity][phi 0..JM-1 | plo 0..JM-1]
+        // what is requested one tap ahead: PIPE = 1 the hi fragments only (224 VGPRs), PIPE = 3 both planes (234): both fit the 256 of two
+        // waves per SIMD once the nine taps of a chunk are unrolled with the tap known at compile time (a runtime tap counter left
+        // hipcc unable to see that nothing is requested across a chunk boundary: 256 VGPRs + 300-400 spilled)
+        constexpr int PFW = PIPE, PFN = (PFW == 3 ? 2 : 1) * JM;
+        u32x4_t wf[2][2];        // two (wh, wl) pairs in flight: the pair of n-tile j + 2 is requested behind the MFMAs of n-tile j
+        const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
+        const unsigned aH = lds0 + fg * FGS + (unsigned)((wm * JM) * HC + fr) * 16;
+        const unsigned aW = lds0 + HALO + lane * 16 + wn * JN * 1024;
+        // which = 1: the hi fragments, 2: the lo fragments, 3: both (hi first); T = tap (compile time: the nine taps of a chunk are unrolled)
+        auto rd_px = [&](auto set_, auto which_, auto t_) __attribute__((always_inline)) {
+            constexpr int S = decltype(set_)::value, WH = decltype(which_)::value, T = decltype(t_)::value;
+            constexpr int OFFT = ((T / KS) * HC + (T % KS)) * 16;
+            if constexpr (WH & 1) cf_static_for<0, JM>([&](auto i_) { px[S][decltype(i_)::value] = cf_lds_rd<OFFT + decltype(i_)::value * HC * 16>(aH); });
+            if constexpr (WH & 2) cf_static_for<0, JM>([&](auto i_) { px[S][JM + decltype(i_)::value] = cf_lds_rd<OFFT + PLANE + decltype(i_)::value * HC * 16>(aH); });
+        };
+        // one step = tap T of the current chunk; S = T & 1 is the pixel set it consumes, PF = the next tap's fragments are requested here.
+        // LDS operations in issue order: [this tap's pixels not requested ahead] w0 w1 [next tap's] w2 w3; they return in order, so
+        // "pair j landed" is lgkmcnt <= what was issued behind it.
+        auto step = [&](auto t_, int wbuf, int s, bool halo_next) __attribute__((always_inline)) {
+            constexpr int T = decltype(t_)::value, S = T & 1, PF = T + 1 < TAPS ? 1 : 0;
+            static_assert(JN == 4, "pipelined form: four n-tiles per wave");
+            const unsigned a0 = aW + (unsigned)wbuf * WT;
+            wf[0][0] = cf_lds_rd<0 * 1024>(a0);
+            wf[0][1] = cf_lds_rd<(BN / 16 + 0) * 1024>(a0);
+            wf[1][0] = cf_lds_rd<1 * 1024>(a0);
+            wf[1][1] = cf_lds_rd<(BN / 16 + 1) * 1024>(a0);
+            dma_w(s + 1, wbuf ^ 1);                 // (buffer wbuf^1 was last read one step ago, by every wave)
+            if constexpr (PF) rd_px(std::integral_constant<int, S ^ 1>{}, std::integral_constant<int, PFW>{}, std::integral_constant<int, T + 1>{});
+            if (halo_next) CF_GLOAD_HALO(kc + 1);
+            cf_static_for<0, JN>([&](auto j_) {
+                constexpr int J = decltype(j_)::value, SL = J & 1;
+                cf_wait_lgkm<J == 0 ? 2 + PFN * PF : (J == 1 ? PFN * PF + 2 : (J == 2 ? 2 : 0))>();
+                if constexpr (J == 0) cf_static_for<0, 2 * JM>([&](auto i_) { cf_touch(px[S][decltype(i_)::value]); });
+                cf_touch(wf[SL][0]);
+                cf_touch(wf[SL][1]);
+                const uint4 wh = cf_u4(wf[SL][0]), wl = cf_u4(wf[SL][1]);
+#pragma unroll
+                for (int i = 0; i < JM; ++i) {
+                    const uint4 phi = cf_u4(px[S][i]), plo = cf_u4(px[S][JM + i]);
+                    acc[J][i] = BF16::mma(wl, phi, acc[J][i]);
+                    acc[J][i] = BF16::mma(wh, plo, acc[J][i]);
+                    acc[J][i] = BF16::mma(wh, phi, acc[J][i]);
+                }
+                if constexpr (J + 2 < JN) {          // the pair two n-tiles ahead, into the registers this n-tile's MFMAs have consumed
+                    wf[SL][0] = cf_lds_rd<(J + 2) * 1024>(a0);
+                    wf[SL][1] = cf_lds_rd<(BN / 16 + J + 2) * 1024>(a0);
+                }
+            });
+        };
+        dma_w(0, 0);
+        CF_GLOAD_HALO(0);
+        int s = 0;
+        for (kc = 0; kc < nkc; ++kc) {
+            store_halo();      // (waits for the raw halo loads and, in program order before them, the DMA of this step)
+            __syncthreads();
+            const bool more = kc + 1 < nkc;
+            rd_px(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{});
+            cf_static_for<0, TAPS>([&](auto t_) {
+                constexpr int T = decltype(t_)::value;
+                if constexpr (T > 0 && (3 & ~PFW) != 0)   // what tap T - 1 did not request ahead
+                    rd_px(std::integral_constant<int, T & 1>{}, std::integral_constant<int, 3 & ~PFW>{}, t_);
+                step(t_, s & 1, s, more && T == 0);
+                // own DMA of step s+1 landed (the halo loads issued after it may stay in flight), then everybody's
+                if (more && T == 0) {
+                    if (a.coef) wait_vmcnt<2 * ITER + 4>(); else wait_vmcnt<2 * ITER>();
+                } else {
+                    wait_vmcnt<0>();
+                }
+                __builtin_amdgcn_s_barrier();
+                ++s;
+            });
+        }
+    } else if constexpr (DMA) {
         dma_w(0, 0);
         CF_GLOAD_HALO(0);
         for (int s = 0; s < nsteps; ++s) {
@@ -400,20 +501,20 @@ __global__ __launch_bounds__(64 * NWV, NWV / 2) void conv_fused_kernel(ConvFArgs
     }
 }
 
-template <int JN, int WNW, int KS, int NWV, bool DMA = false>
+template <int JN, int WNW, int KS, int NWV, bool DMA = false, int PIPE = 0>
 static int launch_cf(const ConvFArgs& a, int B, hipStream_t st) {
     constexpr int PAD = KS / 2, NP = (8 + 2 * PAD) * (16 + 2 * PAD), NPP = (NP + 15) / 16 * 16;
     constexpr int BN = WNW * JN * 16;
     constexpr size_t lds = 2 * 4 * NPP * 16 + 2 * 2 * (BN / 16) * 1024;
     if (a.Npad % BN) return LGEN_ERR_BAD_ARG;
     dim3 grid(a.ntiles, a.Npad / BN, B);
-    hipLaunchKernelGGL((conv_fused_kernel<JN, WNW, KS, NWV, DMA>), grid, dim3(64 * NWV), lds, st, a);
+    hipLaunchKernelGGL((conv_fused_kernel<JN, WNW, KS, NWV, DMA, PIPE>), grid, dim3(64 * NWV), lds, st, a);
     LGEN_CHECK_LAUNCH();
     return 0;
 }
 
-static int g_cf_dma = 1;  // weight tiles by LDS-DMA (1) or through staging registers (0); lgen_debug_set_conv_fused_variant
-extern "C" int lgen_debug_set_conv_fused_variant(int v) { g_cf_dma = v ? 1 : 0; return 0; }
+static int g_cf_dma = 3;  // (default 3 since round 6: 128 -> 128 at 384 px 4.2-4.45 -> 3.95 ms, decode_code 52.4-53.7 -> 50.8 ms, bit-identical: profiles/r06_conv_pipe_ab.log) weight tiles by LDS-DMA (1, 2, 3) or through staging registers (0); 2 / 3: the pipelined fragment reads (3x3, 128 channels) with the hi / both pixel planes requested one tap ahead; lgen_debug_set_conv_fused_variant
+extern "C" int lgen_debug_set_conv_fused_variant(int v) { g_cf_dma = v < 0 || v > 3 ? 3 : v; return 0; }
 
 // weight tile width (output channels per workgroup) this library uses for a given Cout: the host packs to it
 extern "C" int lgen_conv_fused_bn(int Cout) { return Cout >= 128 ? 128 : (Cout > 16 ? 64 : 16); }
@@ -433,6 +534,8 @@ extern "C" int lgen_conv_fused(const float* x_nhwc, const float* gn_coef, int sw
     // 4 waves x (64 ch x 64 px).  Measured alternative: 8 waves x (32 ch x 64 px) per workgroup (4 waves per SIMD instead of 2)
     // runs at the same speed (2.54 vs 2.57 ms, 16 x 384 px, 128 -> 128): the kernel is not short of waves to hide latency.
     if (bn == 128) {
+        if (g_cf_dma == 2 && ksize == 3) return launch_cf<4, 2, 3, 4, true, 1>(a, B, st);
+        if (g_cf_dma == 3 && ksize == 3) return launch_cf<4, 2, 3, 4, true, 3>(a, B, st);
         if (g_cf_dma) return ksize == 3 ? launch_cf<4, 2, 3, 4, true>(a, B, st) : launch_cf<4, 2, 1, 4, true>(a, B, st);
         return ksize == 3 ? launch_cf<4, 2, 3, 4>(a, B, st) : launch_cf<4, 2, 1, 4>(a, B, st);
     }

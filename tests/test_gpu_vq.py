@@ -335,6 +335,21 @@ def test_conv_fused_vs_fp32_reference(B, H, W, Cin, Cout, k, ups, res, nchw, gn)
                                 L.ptr(part), B, H, W, Cin, Cout, cw.fnpad, k, ups, nchw, L.stream()), "conv_fused")
     got = out.cpu().view(B, Cout, H, W) if nchw else out.cpu().view(B, H, W, Cout).permute(0, 3, 1, 2)
     assert torch.isfinite(got).all()   # every pixel of the map was written (masked tile columns included)
+    if k == 3 and Cout >= 128:
+        # round 6: the default weight / fragment staging (variant 3: LDS-DMA + fragment reads pipelined one tap ahead) and the older forms
+        # (2: hi plane ahead only, 1: all reads in front of a tap's MFMAs, 0: staging registers) accumulate every output element in the
+        # same order: bit-identical outputs and statistics partials
+        try:
+            for v in (2, 1, 0):
+                lib.lgen_debug_set_conv_fused_variant(v)
+                out_v = torch.full_like(out, float("nan"))
+                part_v = torch.full_like(part, float("nan"))
+                L.check(lib.lgen_conv_fused(L.ptr(xd), L.ptr(coef), 1 if gn else 0, L.ptr(cw.frag), L.ptr(cw.bias), L.ptr(r_d), L.ptr(out_v),
+                                            L.ptr(part_v), B, H, W, Cin, Cout, cw.fnpad, k, ups, nchw, L.stream()), f"conv_fused variant {v}")
+                assert torch.equal(out_v, out), ("variant", v)
+                assert torch.equal(torch.nan_to_num(part_v, nan=-7.0), torch.nan_to_num(part, nan=-7.0)), ("variant partials", v)
+        finally:
+            lib.lgen_debug_set_conv_fused_variant(3)
     err = (got - ref).abs().max().item()
     assert err < 6e-5 * max(1.0, ref.abs().max().item()), err
     # statistics of what was stored, per (image, tile, 4-channel quad): (sum, M2 about the tile's own mean)

@@ -619,7 +619,8 @@ class DecodeEngine:
         """(statistics buffer, partials per row) for a fused-norm consumer of the TILE family: the producer's rows as they are where
         the consumers' fast path takes them, else their 4 lane-group sums, computed here by one small launch (bit-identical)."""
         parts = self.ssq_parts
-        if parts % 16 == 0 and parts <= 128 or parts % 4 or parts <= 4:
+        fast_path = parts % 16 == 0 and parts <= 128       # the consumers stage such rows in LDS and sum contiguous quarters
+        if fast_path or parts % 4 or parts <= 4:           # (parts % 4: lgen_ssq_group4 does not take the row; the consumer refuses it too)
             return self.ssq, parts
         L.check(self.lib.lgen_ssq_group4(L.ptr(self.ssq), L.ptr(self.ssq_g), self.MTs * 16, parts, L.stream()), "ssq_group4")
         return self.ssq_g, 4
@@ -781,7 +782,7 @@ class DecodeEngine:
         """Kernel launches of one captured decode step (embed + L layers + norm/lm_head + sampler)."""
         per_layer = 5 if self.fuse_norm else 7
         parts = self.d // 16
-        grouped = self.fuse_norm and self._tile_shape("w13") is not None and not (parts % 16 == 0 and parts <= 128 or parts % 4)
+        grouped = self.fuse_norm and self._tile_shape("w13") is not None and not ((parts % 16 == 0 and parts <= 128) or parts % 4 or parts <= 4)
         extra = 2 * len(self.layers) + 1 if grouped else 0   # lgen_ssq_group4 in front of wqkv, w1||w3 and lm_head (GPT-3B)
         return 1 + len(self.layers) * per_layer + (1 if self.fuse_norm else 2) + 1 + extra
 

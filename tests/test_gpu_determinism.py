@@ -5,7 +5,8 @@ GPUTEST_r05 failed on a wrong result that showed up in about one launch of three
 (`gemm_kernel<F16,4,1,EPI_QKV>` at 192 rows: 16 q / k elements per hit) and in none of the others: a packed-fp32 multiply with
 crossed operand selection that MI355X occasionally gets wrong.  A parity test that launches a kernel once
 sees such a fault only by luck; this one launches every case of tools/stress_kernels.py (skinny GEMMs x epilogues x dtypes, fused
-RMSNorm forms, the big-M tile family at 256 / 640 rows, decode attention in both forms, sampler, rmsnorm) 200 times.
+RMSNorm forms, the big-M tile family at 256 / 640 rows, decode attention in both forms, sampler, rmsnorm, and -- round 6 -- the fused
+3x3 convolution with its pipelined fragment reads in every staging variant + the statistics grouping) 200 times.
 tools/stress_kernels.py itself is the long form (5000 launches per case, fresh buffers, a second stream hammering HBM)."""
 import pytest
 import torch
@@ -15,7 +16,7 @@ pytestmark = pytest.mark.gpu
 ITERS = 200
 
 
-@pytest.mark.parametrize("family", ["qkv_cases", "gemm_cases", "tile_cases", "attn_cases", "misc_cases"])
+@pytest.mark.parametrize("family", ["qkv_cases", "gemm_cases", "tile_cases", "attn_cases", "misc_cases", "vq_cases"])
 def test_repeated_launches_are_bit_identical(family):
     from tools import stress_kernels as S
     assert torch.cuda.is_available(), "GPU tests need a real MI355X"

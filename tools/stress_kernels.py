@@ -353,6 +353,46 @@ def misc_cases():
     return out
 
 
+def vq_cases():
+    """Round 6: the fused 3x3 convolution with its hand-ordered fragment reads (counted lgkmcnt waits, one tap ahead: a wait that is one
+    short would be an intermittent wrong result, exactly what this tool looks for) in its default and older staging variants, on a full
+    and on a ragged tile row; the 1x1 form; the row-statistics grouping of GPT-3B (lgen_ssq_group4)."""
+    from llamagen_amd.vq_engine import _ConvW
+    lib = L.lib()
+    out = []
+
+    class Cv:
+        pass
+    for (B, H, W, Cin, Cout, k, gn, res) in ((2, 48, 48, 128, 128, 3, 1, 1), (2, 24, 24, 256, 256, 3, 1, 0), (1, 32, 64, 512, 128, 3, 0, 1),
+                                             (2, 16, 32, 256, 128, 1, 1, 1)):
+        cv = Cv()
+        cv.weight = (rnd((Cout, Cin, k, k), torch.float32, 31) / (Cin * k * k) ** 0.5).to(DEV)
+        cv.bias = (0.1 * rnd((Cout,), torch.float32, 32)).to(DEV)
+        cw = _ConvW(cv)
+        x = (rnd((B, H, W, Cin), torch.float32, 33) * 1.5 + 0.3).to(DEV)
+        r = rnd((B, H, W, Cout), torch.float32, 34).to(DEV)
+        coef = torch.stack([1 + 0.1 * rnd((B, Cin), torch.float32, 35), 0.1 * rnd((B, Cin), torch.float32, 36)], -1).contiguous().to(DEV)
+        ntiles = (H // 8) * ((W + 15) // 16)
+        for variant in ((3, 2, 1) if k == 3 else (3,)):
+            def launch(o, x=x, r=r, coef=coef, cw=cw, variant=variant, B=B, H=H, W=W, Cin=Cin, Cout=Cout, k=k, gn=gn, res=res):
+                lib.lgen_debug_set_conv_fused_variant(variant)
+                try:
+                    return lib.lgen_conv_fused(L.ptr(x), L.ptr(coef) if gn else 0, gn, L.ptr(cw.frag), L.ptr(cw.bias), L.ptr(r) if res else 0, L.ptr(o[0]),
+                                               L.ptr(o[1]), B, H, W, Cin, Cout, cw.fnpad, k, 0, 0, L.stream())
+                finally:
+                    lib.lgen_debug_set_conv_fused_variant(3)
+            # (partials of dropped tile columns are never written: they keep the poison pattern in every launch alike)
+            out.append(Case(f"conv_fused {k}x{k} variant {variant} B{B} {H}x{W} {Cin}->{Cout} gn{gn} res{res}", launch,
+                            lambda B=B, H=H, W=W, Cout=Cout, ntiles=ntiles, cw=cw: [torch.empty(B, H, W, Cout, device=DEV),
+                                                                                    torch.empty(B, ntiles, cw.fnpad // 4, 2, device=DEV)],
+                            [x, r, coef, cw.frag, cw.bias]))
+    for rows, parts in ((512, 200), (256, 96), (64, 4), (128, 256)):
+        ssq = rnd((rows, L.SSQ_STRIDE), torch.float32, 37).abs().to(DEV)
+        out.append(Case(f"ssq_group4 rows{rows} parts{parts}", lambda o, ssq=ssq, rows=rows, parts=parts: lib.lgen_ssq_group4(L.ptr(ssq), L.ptr(o[0]), rows, parts, L.stream()),
+                        lambda rows=rows: [torch.empty(rows, L.SSQ_STRIDE, device=DEV)], [ssq]))
+    return out
+
+
 def sample_signature_ok():
     """lgen_sample's argument order is checked against _lib.SIGNATURES before the sampler case is used"""
     return len(L.SIGNATURES["lgen_sample"]) == 18
@@ -411,7 +451,7 @@ def main():
     assert sample_signature_ok()
     hammer = Hammer() if a.hammer else None
     failed = 0
-    for fam in (qkv_cases, gemm_cases, tile_cases, attn_cases, misc_cases):
+    for fam in (qkv_cases, gemm_cases, tile_cases, attn_cases, misc_cases, vq_cases):
         for c in fam():
             if a.only and a.only not in c.name and a.only not in fam.__name__:
                 continue

@@ -117,13 +117,18 @@ MODEL_TILE_SCHEDULES = {
              "head": (4, 1, 2, 8, 2, 4, 4)}},
     (1280, 3584, 16384): {   # GPT-XL (config 5, t2i)
         16: {"qkv": (4, 1, 1, 4, 4, 4, 4), "wo": (2, 2, 2, 1, 4, 4, 4), "w13": (4, 1, 1, 8, 2, 4, 4), "w2": (2, 2, 2, 1, 4, 4, 4),
+             "head": (8, 1, 1, 8, 2, 4, 4)},
+        # 384 rows (two chains of twelve batches of 16, what bench.py --config 5 runs): 64 x 64 wqkv tiles would be 360 workgroups (two
+        # rounds of the 256 CUs), 64 x 128 w1||w3 tiles 336; 64 x 96 (240) and 128 x 128 (168) fill one -- 21.6 / 21.45 against 21.16 /
+        # 21.25 img/s in the two-chain bench, same box, alternating (profiles/r06_c5_shape_ab2.log)
+        24: {"qkv": (4, 1, 1, 6, 4, 3, 4), "wo": (2, 2, 2, 1, 4, 4, 4), "w13": (4, 1, 2, 8, 2, 4, 4), "w2": (2, 2, 2, 1, 4, 4, 4),
              "head": (8, 1, 1, 8, 2, 4, 4)}},
 }
 # (dim, F, V) -> keys of its table that an end-to-end oracle test runs (tests/test_gpu_headline.py:
 # test_config{3,4}_..._shapes_bf16_vs_oracle[128] / [192]: 256- / 384-row chains; test_config{3,4,5}_wide_chain_shapes_bf16_vs_oracle:
 # the 512- / 512- / 256-row chains bench.py runs since round 6)
 TESTED_MODEL_SCHEDULES = {TABLE_MODEL: TESTED_TILE_SCHEDULES, (1536, 4096, 16384): (16, 32), (3200, 8704, 16384): (16, 32),
-                          (1280, 3584, 16384): (16,)}
+                          (1280, 3584, 16384): (16, 24)}
 
 
 def tile_schedule_key(mts: int, table=None):

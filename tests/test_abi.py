@@ -214,6 +214,8 @@ def test_pinned_tile_schedules_are_shapes_the_library_takes(lib):
     assert b3w._tile_shape("w2") == (2, 2, 4, 2, 2, 4, 4) and b3w._tile_shape("qkv") == (4, 1, 2, 10, 2, 4, 4) and b3w.tile_schedule_tested()
     xl = eng(1280, 3584, 16384, 16)                                                 # GPT-XL (config 5): its own table since round 6
     assert xl._tile_shape("qkv") == (4, 1, 1, 4, 4, 4, 4) and xl.tile_schedule_source() == "table" and xl.tile_schedule_tested()
+    xl384 = eng(1280, 3584, 16384, 24)                                              # 2 x 12 batches of 16: its own key
+    assert xl384._tile_shape("w13") == (4, 1, 2, 8, 2, 4, 4) and xl384.tile_schedule_tested() and eng(1280, 3584, 16384, 20)._tile_shape("w13") == (4, 1, 1, 8, 2, 4, 4)
     other = eng(768, 2048, 16384, 16)                                               # GPT-B: no table of its own -> GPT-L's shapes by width
     assert other._tile_shape("wo") == TILE_SCHEDULES[16]["wo"] and not other.tile_schedule_tested()
     assert other.tile_schedule_source().startswith("table (GPT-L")

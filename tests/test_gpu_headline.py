@@ -800,17 +800,18 @@ def test_config3_gptxxl_shapes_bf16_vs_oracle(B):
     _check(f"config3_gptxxl_shapes_b{B}", recs)
 
 
-@pytest.mark.parametrize("model", ["XXL", "3B", "XL-t2i"])
+@pytest.mark.parametrize("model", ["XXL", "3B", "XL-t2i", "XL-t2i-384"])
 def test_configs_3_4_5_wide_chain_shapes_bf16_vs_oracle(model):
     """Round 6: the chain widths `bench.py --config 3 / 4 / 5` runs now -- GPT-XXL two chains of eight batches of 32 (512 rows), GPT-3B
     two chains of four batches of 64 (512 rows), GPT-XL t2i two chains of eight batches of 16 (256 rows, T = 120 caption tokens with
-    left-padded emb_masks) -- on the shapes engine.MODEL_TILE_SCHEDULES pins for that model and width (keys 32 / 32 / 16, measured with
+    left-padded emb_masks) -- on the shapes engine.MODEL_TILE_SCHEDULES pins for that model and width (keys 32 / 32 / 16 and 24, measured with
     tools/gemm_tile_sweep.py).  Depth cut to 2 layers and the token grid to 16 x 16 (block_size 256; the GEMM shapes do not depend on
     either) so that two CPU oracles of 512 rows stay within ~15 GB and a minute; the 384 / 512 px slab lengths are held by the 128- /
     192- / 32-row cases above and the full-depth goldens below."""
-    if model == "XL-t2i":
+    if model.startswith("XL-t2i"):
         kw = dict(n_layer=2, n_head=20, dim=1280, vocab_size=16384, block_size=256, cls_token_num=120, caption_dim=2048, model_type="t2i")
-        B, T, scale, key, late = 128, 120, 7.5, 16, [370]
+        # 256 rows (key 16), or the 384 rows bench.py --config 5 runs (2 x 12 batches of 16: key 24)
+        B, T, scale, key, late = (192, 120, 7.5, 24, [370]) if model.endswith("384") else (128, 120, 7.5, 16, [370])
         g = torch.Generator().manual_seed(15)
         emb = torch.randn(B, T, 2048, generator=g)
         lens = torch.randint(5, T + 1, (B,), generator=g)

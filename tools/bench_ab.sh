@@ -11,7 +11,7 @@ F="--no-cpu-baseline --no-live-traffic --no-solo --no-one-chain --no-other-confi
 for arm in "$@"; do
   name="${arm%%:*}"; envs="${arm#*:}"
   echo -n "$name: "
-  ( IFS='|'; set -f; for kv in $envs; do [ -n "$kv" ] && export "$kv"; done; timeout 900 python bench.py $F 2>gpurun_out/bench_ab_err.log ) | python -c "
+  ( IFS='|'; set -f; for kv in $envs; do [ -n "$kv" ] && export "$kv"; done; IFS=$' \t\n'; timeout 900 python bench.py $F 2>gpurun_out/bench_ab_err.log ) | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['config']['batches_per_chain'], d['config']['chains_in_flight_per_gpu'])" || tail -3 gpurun_out/bench_ab_err.log
 done 2>&1 | tee -a gpurun_out/bench_ab.log
